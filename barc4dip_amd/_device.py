@@ -1,0 +1,49 @@
+"""Host<->device plumbing: accept NumPy arrays or ROCm torch tensors, hand out device pointers.
+
+PyTorch is used only for device memory, streams and (elsewhere) torch.distributed; all compute
+goes through the C ABI in _ffi.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+def is_tensor(a) -> bool:
+    try:
+        import torch
+    except Exception:  # pragma: no cover
+        return False
+    return isinstance(a, torch.Tensor)
+
+
+def to_device_f32(a, *, ndim: tuple[int, ...]):
+    """Return (contiguous float32 CUDA tensor, was_tensor, numpy_dtype_of_input)."""
+    torch = _ffi.require_gpu()
+    if is_tensor(a):
+        if a.is_complex():
+            raise NotImplementedError("complex input is not supported by the HIP path (real frames only).")
+        if a.ndim not in ndim:
+            raise ValueError(f"expected ndim in {ndim}, got {a.ndim}")
+        src_dtype = np.float64 if a.dtype == torch.float64 else np.float32
+        return a.to(device="cuda", dtype=torch.float32).contiguous(), True, src_dtype
+    arr = np.asarray(a)
+    if np.iscomplexobj(arr):
+        raise NotImplementedError("complex input is not supported by the HIP path (real frames only).")
+    if arr.ndim not in ndim:
+        raise ValueError(f"expected ndim in {ndim}, got {arr.ndim}")
+    src_dtype = np.float64 if arr.dtype == np.float64 else np.float32
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to("cuda", non_blocking=False)
+    return t, False, src_dtype
+
+
+def ptr(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def to_host(t, dtype=None) -> np.ndarray:
+    out = t.detach().cpu().numpy()
+    return out.astype(dtype, copy=False) if dtype is not None else out

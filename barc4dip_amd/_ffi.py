@@ -1,0 +1,166 @@
+"""ctypes binding of include/b4d.h (the C ABI of the gfx950 kernels).
+
+The product path has no CPU fallback: if the shared library is missing or a GPU is not
+present, every compute entry point raises (`B4DUnavailable`).  Build with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C barc4dip_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libb4d.so")
+
+REMOVE_MEAN = 1
+NORM_PEAK = 2
+STANDARDIZE = 4
+
+
+class B4DUnavailable(RuntimeError):
+    """The HIP extension (libb4d.so) or the GPU is missing; there is no CPU fallback."""
+
+
+class B4DError(RuntimeError):
+    pass
+
+
+class B4DSizeError(B4DError, NotImplementedError):
+    """(ny, nx) has no native plan."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+_vp, _i, _u, _f, _d, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol declared in include/b4d.h
+SIGNATURES = {
+    "b4d_version": (C.c_char_p, []),
+    "b4d_last_error": (C.c_char_p, []),
+    "b4d_size_supported": (_i, [_i, _i]),
+    "b4d_plan_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "b4d_plan_destroy": (_i, [_vp]),
+    "b4d_plan_workspace_bytes": (_sz, [_vp]),
+    "b4d_fft2d": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "b4d_psd2d": (_i, [_vp, _vp, _i, _vp, _f, _vp]),
+    "b4d_autocorr2d": (_i, [_vp, _vp, _i, _vp, _u, _vp]),
+    "b4d_psd_autocorr2d": (_i, [_vp, _vp, _i, _vp, _f, _vp, _u, _vp]),
+    "b4d_xcorr2d": (_i, [_vp, _vp, _vp, _i, _vp, _u, _vp]),
+    "b4d_phase_correlation": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp]),
+    "b4d_temporal_accumulate": (_i, [_vp, _i, _sz, _vp, _vp, _vp]),
+    "b4d_temporal_finalize": (_i, [_vp, _vp, _d, _sz, _vp, _vp, _vp, _vp]),
+    "b4d_moments": (_i, [_vp, _i, _sz, _d, _d, _vp, _vp]),
+    "b4d_sobel_laplace_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+}
+
+
+def load_library(path: str | None = None):
+    """dlopen libb4d.so and attach prototypes.  Does not touch the GPU."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise B4DUnavailable(
+                f"{p} not found: the HIP extension is not built (run __graft_entry__.build()). "
+                "barc4dip_amd has no CPU fallback.")
+        lib = C.CDLL(p)
+        missing = []
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:        # header/library drift; tests assert this list is empty
+                missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        lib.b4d_missing_symbols = tuple(missing)
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def lib():
+    return load_library()
+
+
+def check(rc: int):
+    if rc == 0:
+        return
+    msg = lib().b4d_last_error().decode("utf-8", "replace")
+    if rc == -2:
+        raise B4DSizeError(msg)
+    raise B4DError(f"b4d error {rc}: {msg}")
+
+
+def require_gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise B4DUnavailable("no ROCm device visible: barc4dip_amd computes on the GPU only (no CPU fallback).")
+    return torch
+
+
+class Plan:
+    """RAII wrapper of b4d_plan (twiddles + chunk workspace) for one (ny, nx)."""
+
+    def __init__(self, ny: int, nx: int, chunk: int = 8):
+        require_gpu()
+        self.ny, self.nx, self.chunk = int(ny), int(nx), int(chunk)
+        h = _vp()
+        check(lib().b4d_plan_create(self.ny, self.nx, self.chunk, C.byref(h)))
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def workspace_bytes(self) -> int:
+        return int(lib().b4d_plan_workspace_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().b4d_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_plans: dict = {}
+_plans_lock = threading.Lock()
+
+
+def supported(ny: int, nx: int) -> bool:
+    return bool(lib().b4d_size_supported(int(ny), int(nx)))
+
+
+def default_chunk(ny: int, nx: int) -> int:
+    """Frames per launch group: keep spectrum + outputs of a chunk inside the 256 MiB Infinity Cache
+    while still filling 256 CUs (>= ~1024 workgroups per launch)."""
+    per_frame = ny * nx * 4
+    return max(1, min(64, (96 << 20) // per_frame))
+
+
+def get_plan(ny: int, nx: int, chunk: int | None = None) -> Plan:
+    import torch
+
+    key = (int(ny), int(nx), int(chunk or default_chunk(ny, nx)), torch.cuda.current_device())
+    with _plans_lock:
+        pl = _plans.get(key)
+        if pl is None:
+            pl = Plan(key[0], key[1], key[2])
+            _plans[key] = pl
+        return pl
+
+
+def stream_ptr():
+    import torch
+
+    return _vp(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,252 @@
+// b4d_fft.hpp -- register/LDS FFT building blocks for gfx950 (wave64, 160 KiB LDS per CU).
+//
+// One transform of length N is held by T = N/E lanes, E complex points per lane, in the
+// "strided" layout  lane u, register j  <->  element u + T*j   (input AND output).
+// Three register stages (radices R1*R2*R3 = N) are separated by two LDS exchanges:
+//
+//   stage 1  n = n1 + M*n2 (M = N/R1):  DFT_R1 over n2, twiddle w_N^(n1*k2)
+//   stage 2  n1 = m1 + R3*m2:           DFT_R2 over m2, twiddle w_M^(m1*q2)
+//   stage 3                             DFT_R3 over m1        k = k2 + R1*(q2 + R2*q1)
+//
+// The exchange buffers are padded (S1, S2) so that every ds_read_b64 / ds_write_b64 of a
+// wave is bank-conflict free; CI "interleaved" transforms (the column kernels keep CI
+// column pairs in adjacent lanes so that global accesses are whole 128-B lines) share one
+// buffer with the interleave index as the fastest LDS dimension.
+//
+// Inverse transforms use the same code on (im, re)-swapped data: ifft(x) = swap(fft(swap(x))).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace b4d {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cswap(float2 a) { return make_float2(a.y, a.x); }
+// multiply by -i (forward-direction quarter turn)
+__device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+#define B4D_SQRT1_2 0.70710678118654752440f
+#define B4D_C1_16 0.92387953251128675613f  // cos(pi/8)
+#define B4D_S1_16 0.38268343236508977173f  // sin(pi/8)
+#define B4D_C1_32 0.98078528040323044913f  // cos(pi/16)
+#define B4D_S1_32 0.19509032201612826785f  // sin(pi/16)
+#define B4D_C3_32 0.83146961230254523708f  // cos(3pi/16)
+#define B4D_S3_32 0.55557023301960222474f  // sin(3pi/16)
+
+// ---- small DFTs, natural order in and out, forward sign exp(-2 pi i nk/R) -------------
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<1> {
+    static __device__ __forceinline__ void run(float2 (&x)[1]) {}
+};
+
+template <>
+struct Dft<2> {
+    static __device__ __forceinline__ void run(float2 (&x)[2]) {
+        float2 a = x[0], b = x[1];
+        x[0] = cadd(a, b);
+        x[1] = csub(a, b);
+    }
+};
+
+template <>
+struct Dft<4> {
+    static __device__ __forceinline__ void run(float2 (&x)[4]) {
+        float2 t0 = cadd(x[0], x[2]), t1 = csub(x[0], x[2]);
+        float2 t2 = cadd(x[1], x[3]), t3 = cmul_mi(csub(x[1], x[3]));
+        x[0] = cadd(t0, t2);
+        x[2] = csub(t0, t2);
+        x[1] = cadd(t1, t3);
+        x[3] = csub(t1, t3);
+    }
+};
+
+template <>
+struct Dft<8> {
+    static __device__ __forceinline__ void run(float2 (&x)[8]) {
+        float2 e[4] = {x[0], x[2], x[4], x[6]};
+        float2 o[4] = {x[1], x[3], x[5], x[7]};
+        Dft<4>::run(e);
+        Dft<4>::run(o);
+        // w8^1 = (1-i)/sqrt2, w8^2 = -i, w8^3 = (-1-i)/sqrt2
+        float2 o1 = make_float2((o[1].x + o[1].y) * B4D_SQRT1_2, (o[1].y - o[1].x) * B4D_SQRT1_2);
+        float2 o2 = cmul_mi(o[2]);
+        float2 o3 = make_float2((o[3].y - o[3].x) * B4D_SQRT1_2, -(o[3].x + o[3].y) * B4D_SQRT1_2);
+        x[0] = cadd(e[0], o[0]);
+        x[4] = csub(e[0], o[0]);
+        x[1] = cadd(e[1], o1);
+        x[5] = csub(e[1], o1);
+        x[2] = cadd(e[2], o2);
+        x[6] = csub(e[2], o2);
+        x[3] = cadd(e[3], o3);
+        x[7] = csub(e[3], o3);
+    }
+};
+
+template <>
+struct Dft<16> {
+    static __device__ __forceinline__ void run(float2 (&x)[16]) {
+        // decimation in time, 4 x 4: s_r[m] = x[4m + r]
+        float2 s[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float2 t[4] = {x[r], x[r + 4], x[r + 8], x[r + 12]};
+            Dft<4>::run(t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[r][k] = t[k];
+        }
+        // twiddles w16^(r*k)
+        const float2 w1 = make_float2(B4D_C1_16, -B4D_S1_16);
+        const float2 w2 = make_float2(B4D_SQRT1_2, -B4D_SQRT1_2);
+        const float2 w3 = make_float2(B4D_S1_16, -B4D_C1_16);
+        const float2 w6 = make_float2(-B4D_SQRT1_2, -B4D_SQRT1_2);
+        const float2 w9 = make_float2(-B4D_C1_16, B4D_S1_16);
+        s[1][1] = cmul(s[1][1], w1);
+        s[1][2] = cmul(s[1][2], w2);
+        s[1][3] = cmul(s[1][3], w3);
+        s[2][1] = cmul(s[2][1], w2);
+        s[2][2] = cmul_mi(s[2][2]);
+        s[2][3] = cmul(s[2][3], w6);
+        s[3][1] = cmul(s[3][1], w3);
+        s[3][2] = cmul(s[3][2], w6);
+        s[3][3] = cmul(s[3][3], w9);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float2 t[4] = {s[0][k], s[1][k], s[2][k], s[3][k]};
+            Dft<4>::run(t);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[k + 4 * q] = t[q];
+        }
+    }
+};
+
+// ---- plan geometry ---------------------------------------------------------------------
+template <int N_, int E_, int R1_, int R2_, int R3_, int CI_>
+struct FftGeom {
+    static constexpr int N = N_, E = E_, R1 = R1_, R2 = R2_, R3 = R3_, CI = CI_;
+    static constexpr int T = N / E;   // lanes per transform
+    static constexpr int M = N / R1;  // length of the stage-2/3 sub-transform
+    static_assert(R1 * R2 * R3 == N, "radices must multiply to N");
+    static_assert(E % R1 == 0 && E % R2 == 0 && E % R3 == 0, "each radix must divide E");
+    // exchange strides (complex elements), chosen for conflict-free b64 access:
+    //  CI == 1 (lanes run along the transform):  S1 == 2 (mod 32), S2 == 16 (mod 32)
+    //  CI >= 4 (interleave index fastest):        S1 odd,          S2 unpadded
+    static constexpr int S1 = (CI == 1) ? (M + 2) : (M + 1);
+    static constexpr int S2 = (CI == 1) ? (R1 * R3 + 16) : (R1 * R3);
+    static constexpr int X1 = R1 * S1, X2 = R2 * S2;
+    static constexpr int LDS_ELEMS = (X1 > X2 ? X1 : X2) > N ? (X1 > X2 ? X1 : X2) : N;  // per transform
+};
+
+// Three-stage forward FFT on one or two register sets that share lane geometry.
+// `u` = lane position along the transform (0..T-1); `lds` = this transform group's buffer;
+// LDS element address = logical_address * CI + ci.   NV = number of register sets (1 or 2):
+// with NV == 2 the two sets go through the buffer one after the other.
+template <class G, int NV>
+struct Fft3 {
+    static constexpr int E = G::E, T = G::T, R1 = G::R1, R2 = G::R2, R3 = G::R3, CI = G::CI;
+
+    template <int R, int CNT, int STRIDE>
+    static __device__ __forceinline__ void butterflies(float2 (&v)[E]) {
+        // CNT butterflies of radix R on registers i + STRIDE*n  (i = 0..CNT-1, n = 0..R-1)
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            float2 t[R];
+#pragma unroll
+            for (int n = 0; n < R; ++n) t[n] = v[i + STRIDE * n];
+            Dft<R>::run(t);
+#pragma unroll
+            for (int n = 0; n < R; ++n) v[i + STRIDE * n] = t[n];
+        }
+    }
+
+    // stage 1 on one register set: register j = i + B1*n2, n1 = u + T*i; then twiddle w_N^(n1*k2)
+    static __device__ __forceinline__ void stage1(float2 (&v)[E], int u, const float2* __restrict__ tw) {
+        constexpr int B1 = E / R1;
+        butterflies<R1, B1, B1>(v);
+#pragma unroll
+        for (int i = 0; i < B1; ++i) {
+            const int n1 = u + T * i;
+#pragma unroll
+            for (int k2 = 1; k2 < R1; ++k2) v[i + B1 * k2] = cmul(v[i + B1 * k2], tw[n1 * k2]);
+        }
+    }
+    // exchange 1: addr1(k2, n1) = k2*S1 + n1 ; stage-2 combos c = k2 + R1*m1, lane u handles c = u + T*i2
+    static __device__ __forceinline__ void xchg1(float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
+        constexpr int B1 = E / R1, B2 = E / R2;
+#pragma unroll
+        for (int i = 0; i < B1; ++i)
+#pragma unroll
+            for (int k2 = 0; k2 < R1; ++k2) lds[(k2 * G::S1 + u + T * i) * CI + ci] = v[i + B1 * k2];
+        __syncthreads();
+#pragma unroll
+        for (int i2 = 0; i2 < B2; ++i2) {
+            const int c = u + T * i2, k2 = c % R1, m1 = c / R1;
+#pragma unroll
+            for (int m2 = 0; m2 < R2; ++m2) v[i2 + B2 * m2] = lds[(k2 * G::S1 + m1 + R3 * m2) * CI + ci];
+        }
+    }
+    // stage 2: DFT over m2, twiddle w_M^(m1*q2) = w_N^(R1*m1*q2)
+    static __device__ __forceinline__ void stage2(float2 (&v)[E], int u, const float2* __restrict__ tw) {
+        constexpr int B2 = E / R2;
+        butterflies<R2, B2, B2>(v);
+#pragma unroll
+        for (int i2 = 0; i2 < B2; ++i2) {
+            const int m1 = (u + T * i2) / R1;
+#pragma unroll
+            for (int q2 = 1; q2 < R2; ++q2) v[i2 + B2 * q2] = cmul(v[i2 + B2 * q2], tw[R1 * m1 * q2]);
+        }
+    }
+    // exchange 2: addr2(q2, m1, k2) = q2*S2 + c ; stage-3 butterflies A = k2 + R1*q2, lane u handles A = u + T*a
+    static __device__ __forceinline__ void xchg2(float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
+        constexpr int B2 = E / R2, B3 = E / R3;
+#pragma unroll
+        for (int i2 = 0; i2 < B2; ++i2)
+#pragma unroll
+            for (int q2 = 0; q2 < R2; ++q2) lds[(q2 * G::S2 + u + T * i2) * CI + ci] = v[i2 + B2 * q2];
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < B3; ++a) {
+            const int A = u + T * a, k2 = A % R1, q2 = A / R1;
+#pragma unroll
+            for (int m1 = 0; m1 < R3; ++m1) v[a + B3 * m1] = lds[(q2 * G::S2 + m1 * R1 + k2) * CI + ci];
+        }
+    }
+    // stage 3: outputs q1 -> register a + B3*q1  <->  k = u + T*(a + B3*q1)
+    static __device__ __forceinline__ void stage3(float2 (&v)[E]) { butterflies<R3, E / R3, E / R3>(v); }
+
+    // The caller guarantees nobody still reads `lds` on entry; on exit other lanes may still be
+    // reading it (sync before reuse).  With NV == 2 the sets are processed strictly one after
+    // the other (sched_barrier keeps the compiler from interleaving them: the column kernels run
+    // at the 128-VGPR cap of a 1024-lane workgroup).
+    static __device__ __forceinline__ void run(float2 (&va)[E], float2 (&vb)[E], int u, int ci,
+                                               float2* __restrict__ lds, const float2* __restrict__ tw) {
+        stage1(va, u, tw);
+        xchg1(va, u, ci, lds);
+        if (NV == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage1(vb, u, tw);
+            __syncthreads();
+            xchg1(vb, u, ci, lds);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage2(va, u, tw);
+        __syncthreads();
+        xchg2(va, u, ci, lds);
+        if (NV == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage2(vb, u, tw);
+            __syncthreads();
+            xchg2(vb, u, ci, lds);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage3(va);
+        if (NV == 2) stage3(vb);
+    }
+};
+
+}  // namespace b4d

@@ -1,0 +1,113 @@
+/* b4d.h -- C ABI of the MI355X (gfx950) hot path of barc4dip.
+ *
+ * The reference (barc4dip, pure Python) has no FFI: its boundary is the Python API of
+ * barc4dip.signal / barc4dip.metrics / barc4dip.preprocessing.  This header is what a
+ * maintainer binds (ctypes) to route those functions to the GPU.
+ * Each entry point cites the reference function it serves (paths under
+ * /root/reference/src/barc4dip).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative B4D_E* code on failure; the message
+ *     is available from b4d_last_error() (thread local).  No C++ exceptions cross the ABI.
+ *   - all data pointers are DEVICE pointers owned by the caller (e.g. tensor.data_ptr());
+ *     images are row-major (ny, nx) float32, stacks (batch, ny, nx).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     asynchronous on that stream; a plan may be used from one stream at a time.
+ *   - FFT outputs are fftshift-ed (DC at [ny/2, nx/2]) exactly as signal/fft.py:7-10 and
+ *     signal/corr.py:7-10 define.
+ */
+#ifndef B4D_H
+#define B4D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B4D_OK 0
+#define B4D_EINVAL (-1)   /* bad argument (null pointer, batch <= 0, ...) */
+#define B4D_ESIZE (-2)    /* (ny, nx) not supported by the compiled kernels */
+#define B4D_EHIP (-3)     /* a HIP runtime call failed */
+#define B4D_ENOMEM (-4)
+
+/* flags for b4d_autocorr2 / b4d_psd_autocorr2 (signal/corr.py:169-180 keyword arguments) */
+#define B4D_REMOVE_MEAN 1u      /* remove_mean=True  : zero the DC bin of the power spectrum */
+#define B4D_NORM_PEAK 2u        /* normalize="peak"  : divide by the zero-lag value, peak == 1 */
+#define B4D_STANDARDIZE 4u      /* standardize=True  : divide by the variance (only visible with normalize="none") */
+
+typedef struct b4d_plan b4d_plan;
+
+/* Library / device ------------------------------------------------------------------- */
+const char* b4d_version(void);
+const char* b4d_last_error(void);
+/* 1 if (ny, nx) has a native (power-of-two) plan: ny, nx in {512, 1024, 2048, 4096}. */
+int b4d_size_supported(int ny, int nx);
+
+/* Plans ------------------------------------------------------------------------------
+ * A plan owns the twiddle tables and a workspace of `chunk` half-spectra
+ * (chunk * ny * nx/2 complex64).  Batches larger than `chunk` are processed chunk by
+ * chunk so that intermediates stay in the 256 MiB Infinity Cache.                      */
+int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out);
+int b4d_plan_destroy(b4d_plan* plan);
+size_t b4d_plan_workspace_bytes(const b4d_plan* plan);
+
+/* signal/fft.py:198-237 fft2d -- F = fftshift(fft2(img)) for a batch of real frames.
+ * out: (batch, ny, nx) complex64 interleaved (re, im).                                  */
+int b4d_fft2d(b4d_plan* plan, const float* frames, int batch, float* out_c64, void* stream);
+
+/* signal/fft.py:261-309 psd2d -- P = |fftshift(fft2(img))|^2 * scale, scale = dx*dy/(nx*ny)
+ * when scale=True else 1.  psd: (batch, ny, nx) float32.                                */
+int b4d_psd2d(b4d_plan* plan, const float* frames, int batch, float* psd, float scale, void* stream);
+
+/* signal/corr.py:256-320 autocorr2d -- circular autocorrelation, shifted, float32.
+ * With B4D_NORM_PEAK the zero-lag sample is exactly 1.0f.                               */
+int b4d_autocorr2d(b4d_plan* plan, const float* frames, int batch, float* autocorr, unsigned flags,
+                   void* stream);
+
+/* The north-star pipeline: one forward transform serves psd2d and
+ * autocorr2d.  Either output pointer may be NULL.                                       */
+int b4d_psd_autocorr2d(b4d_plan* plan, const float* frames, int batch, float* psd, float psd_scale,
+                       float* autocorr, unsigned flags, void* stream);
+
+/* signal/corr.py:169-253 xcorr2d -- fftshift(ifft2(fft2(a) * conj(fft2(b)))), real part,
+ * float32.  flags as above (B4D_NORM_PEAK divides by max|corr|).                        */
+int b4d_xcorr2d(b4d_plan* plan, const float* a, const float* b, int batch, float* corr, unsigned flags,
+                void* stream);
+
+/* signal/tracking.py:191-297 phase_correlation (backend="internal") for `npairs`
+ * (image, template) pairs.  images: (nimg, ny, nx) raw frames; templates are cut from
+ * `tpl_src` frames: pair i uses image img_idx[i], template frame tpl_idx[i] and the ROI
+ * roi[i] = {y0, y1, x0, x1}.  z-scoring (tracking.py:308-311), zero-embedding
+ * (geometry/roi.py:175-222), whitening, |ifft2|, first-occurrence arg-max, peak, median
+ * SNR and the 3x3 Taylor step all run on the device.
+ * out: (npairs, 4) float64 rows {dy, dx, peak, snr}; peak_ij: (npairs, 2) int32 or NULL. */
+int b4d_phase_correlation(b4d_plan* plan, const float* images, int nimg, const float* tpl_src, int ntpl,
+                          const int32_t* img_idx, const int32_t* tpl_idx, const int32_t* roi, int npairs,
+                          int subpixel, double eps, double* out, int32_t* peak_ij, void* stream);
+
+/* Temporal per-pixel statistics (io/rw.py:129-132 for the mean).
+ * accumulate: sum_x += sum_t x, sum_xx += sum_t x^2 over `nframes` frames of npix pixels
+ * (float64 accumulators, caller zero-initialises).  finalize: mean, var (ddof 0),
+ * contrast = sqrt(var)/mean as float32 maps from the (all-reduced) sums.                */
+int b4d_temporal_accumulate(const float* frames, int nframes, size_t npix, double* sum_x, double* sum_xx,
+                            void* stream);
+int b4d_temporal_finalize(const double* sum_x, const double* sum_xx, double count, size_t npix, float* mean,
+                          float* var, float* contrast, void* stream);
+
+/* metrics/statistics.py:17-125 distribution_moments + speckles.py:640-645 visibility inputs:
+ * per-frame finite-only power sums in float64.
+ * out: (batch, 8) float64 {n_finite, sum, sum2(centered), sum3(centered), sum4(centered), n_zero, n_sat, min}... see DESIGN.md */
+int b4d_moments(const float* frames, int batch, size_t npix, double eps, double saturation, double* out,
+                void* stream);
+
+/* metrics/sharpness.py:405-530 tenengrad + laplacian_variance: scipy.ndimage sobel/laplace
+ * with mode="reflect", fused with their reductions.
+ * out: (batch, 4) float64 {mean(gx^2), mean(gy^2), mean(lap), mean(lap^2)} over finite pixels. */
+int b4d_sobel_laplace_stats(const float* frames, int batch, int ny, int nx, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B4D_H */
