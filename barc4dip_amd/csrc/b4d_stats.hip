@@ -1,0 +1,373 @@
+// b4d_stats.hip -- streaming reductions of the barc4dip metrics layer on gfx950:
+//   temporal per-pixel sums, finite-only distribution moments
+//   (metrics/statistics.py:17-125), Sobel / Laplace statistics with scipy "reflect"
+//   borders (metrics/sharpness.py:405-530).
+// All of them are HBM-bound single-read passes; float64 accumulation (the reference computes
+// these in float64), wave64 shuffles + one LDS hop per workgroup, and a fixed-order second
+// stage so results are bitwise reproducible (no float atomics).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <mutex>
+#include <string>
+
+#include "../../include/b4d.h"
+#include "b4d_common.hpp"
+
+namespace b4d {
+
+// ------------------------------------------------------------------------------------ scratch
+// Lazily grown per-process device scratch for second-stage reductions (never reallocated on the
+// hot path once it has reached its high-water mark).
+static std::mutex g_scratch_mu;
+static void* g_scratch = nullptr;
+static size_t g_scratch_bytes = 0;
+int get_scratch(size_t bytes, void** out) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (bytes > g_scratch_bytes) {
+        if (g_scratch) (void)hipFree(g_scratch);
+        g_scratch = nullptr;
+        g_scratch_bytes = 0;
+        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        hipError_t e = hipMalloc(&g_scratch, want);
+        if (e != hipSuccess) return fail(B4D_ENOMEM, std::string("scratch allocation: ") + hipGetErrorString(e));
+        g_scratch_bytes = want;
+    }
+    *out = g_scratch;
+    return B4D_OK;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block-wide sum of K doubles per lane; result valid in thread 0.  blockDim.x <= 1024.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* sh /* [16*K] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = wave_sum(v[k]);
+        if (lane == 0) sh[w * K + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double s = 0.0;
+            for (int i = 0; i < nw; ++i) s += sh[i * K + k];
+            v[k] = s;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------ temporal
+// One lane owns 4 adjacent pixels (one 16-B load per frame); frames are walked with 4 loads in flight.
+__global__ void __launch_bounds__(256) k_temporal_acc(const float* __restrict__ frames, int nframes, size_t npix,
+                                                      double* __restrict__ sx, double* __restrict__ sxx) {
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= npix) return;
+    double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (i4 + 3 < npix) {
+        const float* p = frames + i4;
+        int t = 0;
+        for (; t + 4 <= nframes; t += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(p + (size_t)(t + k) * npix);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double x0 = v[k].x, x1 = v[k].y, x2 = v[k].z, x3 = v[k].w;
+                a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3;
+                q[0] = fma(x0, x0, q[0]); q[1] = fma(x1, x1, q[1]); q[2] = fma(x2, x2, q[2]); q[3] = fma(x3, x3, q[3]);
+            }
+        }
+        for (; t < nframes; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)t * npix);
+            const double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+            a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3;
+            q[0] = fma(x0, x0, q[0]); q[1] = fma(x1, x1, q[1]); q[2] = fma(x2, x2, q[2]); q[3] = fma(x3, x3, q[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sx[i4 + k] += a[k];
+            sxx[i4 + k] += q[k];
+        }
+    } else {  // ragged tail
+        for (size_t i = i4; i < npix; ++i) {
+            double s = 0, ss = 0;
+            for (int t = 0; t < nframes; ++t) {
+                const double x = frames[(size_t)t * npix + i];
+                s += x;
+                ss = fma(x, x, ss);
+            }
+            sx[i] += s;
+            sxx[i] += ss;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_temporal_fin(const double* __restrict__ sx, const double* __restrict__ sxx,
+                                                      double count, size_t npix, float* __restrict__ mean,
+                                                      float* __restrict__ var, float* __restrict__ contrast) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const double m = sx[i] / count;
+    double v = sxx[i] / count - m * m;
+    v = v > 0.0 ? v : 0.0;
+    if (mean) mean[i] = (float)m;
+    if (var) var[i] = (float)v;
+    if (contrast) contrast[i] = (float)(sqrt(v) / m);
+}
+
+// ------------------------------------------------------------------------------------ moments
+// pass 1: {n_finite, sum, n_zero, n_sat}; pass 2 (mean known): {sum d^2, sum d^3, sum d^4}
+// grid (split, batch).  partials: [batch][split][4] doubles.
+__global__ void __launch_bounds__(1024) k_moments1(const float* __restrict__ frames, size_t npix, double eps,
+                                                   double sat, double* __restrict__ part) {
+    __shared__ double sh[16 * 4];
+    const float* f = frames + (size_t)blockIdx.y * npix;
+    const size_t n4 = npix / 4;
+    double v[4] = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 q = reinterpret_cast<const float4*>(f)[i];
+        const float xs[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double x = xs[k];
+            if (isfinite(x)) {
+                v[0] += 1.0;
+                v[1] += x;
+                v[2] += (fabs(x) <= eps) ? 1.0 : 0.0;
+                v[3] += (x >= sat) ? 1.0 : 0.0;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (npix & 3)) {
+        const double x = f[n4 * 4 + threadIdx.x];
+        if (isfinite(x)) {
+            v[0] += 1.0;
+            v[1] += x;
+            v[2] += (fabs(x) <= eps) ? 1.0 : 0.0;
+            v[3] += (x >= sat) ? 1.0 : 0.0;
+        }
+    }
+    block_sum<4>(v, sh);
+    if (threadIdx.x == 0) {
+        double* o = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = v[k];
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_moments2(const float* __restrict__ frames, size_t npix,
+                                                   const double* __restrict__ part1, int split1,
+                                                   double* __restrict__ part) {
+    __shared__ double sh[16 * 3];
+    __shared__ double s_mean;
+    if (threadIdx.x == 0) {
+        double n = 0, s = 0;
+        for (int i = 0; i < split1; ++i) {
+            n += part1[((size_t)blockIdx.y * split1 + i) * 4 + 0];
+            s += part1[((size_t)blockIdx.y * split1 + i) * 4 + 1];
+        }
+        s_mean = n > 0 ? s / n : 0.0;
+    }
+    __syncthreads();
+    const double mu = s_mean;
+    const float* f = frames + (size_t)blockIdx.y * npix;
+    const size_t n4 = npix / 4;
+    double v[3] = {0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 q = reinterpret_cast<const float4*>(f)[i];
+        const float xs[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double x = xs[k];
+            if (isfinite(x)) {
+                const double d = x - mu, d2 = d * d;
+                v[0] += d2;
+                v[1] = fma(d2, d, v[1]);
+                v[2] = fma(d2, d2, v[2]);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (npix & 3)) {
+        const double x = f[n4 * 4 + threadIdx.x];
+        if (isfinite(x)) {
+            const double d = x - mu, d2 = d * d;
+            v[0] += d2;
+            v[1] = fma(d2, d, v[1]);
+            v[2] = fma(d2, d2, v[2]);
+        }
+    }
+    block_sum<3>(v, sh);
+    if (threadIdx.x == 0) {
+        double* o = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+        o[0] = v[0];
+        o[1] = v[1];
+        o[2] = v[2];
+    }
+}
+
+// out[b] = {n_finite, mean, sum d^2, sum d^3, sum d^4, n_zero, n_sat, 0}
+__global__ void k_moments_fin(const double* __restrict__ p1, const double* __restrict__ p2, int split,
+                              double* __restrict__ out) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double n = 0, s = 0, nz = 0, ns = 0, m2 = 0, m3 = 0, m4 = 0;
+    for (int i = 0; i < split; ++i) {
+        const double* a = p1 + ((size_t)b * split + i) * 4;
+        const double* c = p2 + ((size_t)b * split + i) * 3;
+        n += a[0]; s += a[1]; nz += a[2]; ns += a[3];
+        m2 += c[0]; m3 += c[1]; m4 += c[2];
+    }
+    double* o = out + (size_t)b * 8;
+    o[0] = n; o[1] = n > 0 ? s / n : 0.0; o[2] = m2; o[3] = m3; o[4] = m4; o[5] = nz; o[6] = ns; o[7] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------ Sobel / Laplace
+// scipy.ndimage "reflect" = half-sample symmetric: index -1 -> 0, n -> n-1.
+__device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }
+
+// grid (ceil(nx/64), ceil(ny/16), batch), block (64, 4): each thread walks 4 rows of one column.
+// partials [batch][gridDim.y*gridDim.x][5] = {n_finite, sum gx^2, sum gy^2, sum lap, sum lap^2}
+__global__ void __launch_bounds__(256) k_sobel_lap(const float* __restrict__ frames, int ny, int nx,
+                                                   double* __restrict__ part) {
+    __shared__ double sh[16 * 5];
+    const float* f = frames + (size_t)blockIdx.z * ny * nx;
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    double v[5] = {0, 0, 0, 0, 0};
+    if (x < nx) {
+        const int xm = refl(x - 1, nx), xp = refl(x + 1, nx);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = blockIdx.y * 16 + threadIdx.y * 4 + r;
+            if (y >= ny) break;
+            const int ym = refl(y - 1, ny), yp = refl(y + 1, ny);
+            const float* rm = f + (size_t)ym * nx;
+            const float* r0 = f + (size_t)y * nx;
+            const float* rp = f + (size_t)yp * nx;
+            const double a = rm[xm], b = rm[x], c = rm[xp];
+            const double d = r0[xm], e = r0[x], g = r0[xp];
+            const double h = rp[xm], i = rp[x], j = rp[xp];
+            if (isfinite(e)) {
+                // scipy sobel(axis=1): derivative [-1,0,1] along x, smoothing [1,2,1] along y
+                const double gx = (c - a) + 2.0 * (g - d) + (j - h);
+                const double gy = (h - a) + 2.0 * (i - b) + (j - c);
+                const double lap = (d + g - 2.0 * e) + (b + i - 2.0 * e);
+                v[0] += 1.0;
+                v[1] = fma(gx, gx, v[1]);
+                v[2] = fma(gy, gy, v[2]);
+                v[3] += lap;
+                v[4] = fma(lap, lap, v[4]);
+            }
+        }
+    }
+    // block_sum indexes by threadIdx.x; flatten the 2-D block
+    {
+        const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            v[k] = wave_sum(v[k]);
+            if (lane == 0) sh[w * 5 + k] = v[k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double* o = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 5;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o[k] = sh[k] + sh[5 + k] + sh[10 + k] + sh[15 + k];
+        }
+    }
+}
+
+// out[b] = {mean gx^2, mean gy^2, mean lap, mean lap^2}; fixed-order tree over the partials.
+__global__ void __launch_bounds__(256) k_sobel_fin(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    __shared__ double sh[16 * 5];
+    const double* p = part + (size_t)blockIdx.x * nblk * 5;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += p[(size_t)i * 5 + k];
+    block_sum<5>(v, sh);
+    if (threadIdx.x == 0) {
+        double* o = out + (size_t)blockIdx.x * 4;
+        const double n = v[0];
+        o[0] = v[1] / n; o[1] = v[2] / n; o[2] = v[3] / n; o[3] = v[4] / n;
+    }
+}
+
+}  // namespace b4d
+
+using namespace b4d;
+
+extern "C" {
+
+int b4d_temporal_accumulate(const float* frames, int nframes, size_t npix, double* sum_x, double* sum_xx,
+                            void* stream) {
+    if (!frames || !sum_x || !sum_xx) return fail(B4D_EINVAL, "null argument");
+    if (nframes < 1 || npix < 1) return fail(B4D_EINVAL, "nframes and npix must be >= 1");
+    if ((reinterpret_cast<uintptr_t>(frames) & 15) || (npix & 3))
+        return fail(B4D_EINVAL, "frames must be 16-byte aligned and npix a multiple of 4");
+    const size_t lanes = (npix + 3) / 4;
+    hipLaunchKernelGGL(k_temporal_acc, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames,
+                       nframes, npix, sum_x, sum_xx);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int b4d_temporal_finalize(const double* sum_x, const double* sum_xx, double count, size_t npix, float* mean,
+                          float* var, float* contrast, void* stream) {
+    if (!sum_x || !sum_xx) return fail(B4D_EINVAL, "null argument");
+    if (!(count > 0)) return fail(B4D_EINVAL, "count must be > 0");
+    hipLaunchKernelGGL(k_temporal_fin, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sum_x,
+                       sum_xx, count, npix, mean, var, contrast);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int b4d_moments(const float* frames, int batch, size_t npix, double eps, double saturation, double* out,
+                void* stream) {
+    if (!frames || !out) return fail(B4D_EINVAL, "null argument");
+    if (batch < 1 || npix < 1) return fail(B4D_EINVAL, "batch and npix must be >= 1");
+    if ((reinterpret_cast<uintptr_t>(frames) & 15) || (npix & 3))
+        return fail(B4D_EINVAL, "frames must be 16-byte aligned and npix a multiple of 4");
+    int split = 2048 / batch;
+    split = split < 1 ? 1 : (split > 256 ? 256 : split);
+    const size_t work = (npix / 4 + 1023) / 1024;
+    if ((size_t)split > work) split = (int)(work ? work : 1);
+    void* ws = nullptr;
+    int rc = get_scratch(sizeof(double) * 7 * (size_t)batch * split, &ws);
+    if (rc) return rc;
+    double* p1 = static_cast<double*>(ws);
+    double* p2 = p1 + (size_t)4 * batch * split;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_moments1, dim3(split, batch), dim3(1024), 0, st, frames, npix, eps, saturation, p1);
+    hipLaunchKernelGGL(k_moments2, dim3(split, batch), dim3(1024), 0, st, frames, npix, p1, split, p2);
+    hipLaunchKernelGGL(k_moments_fin, dim3(batch), dim3(64), 0, st, p1, p2, split, out);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int b4d_sobel_laplace_stats(const float* frames, int batch, int ny, int nx, double* out, void* stream) {
+    if (!frames || !out) return fail(B4D_EINVAL, "null argument");
+    if (batch < 1 || ny < 1 || nx < 1) return fail(B4D_EINVAL, "batch, ny, nx must be >= 1");
+    const dim3 grid((nx + 63) / 64, (ny + 15) / 16, batch);
+    const int nblk = grid.x * grid.y;
+    void* ws = nullptr;
+    int rc = get_scratch(sizeof(double) * 5 * (size_t)batch * nblk, &ws);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sobel_lap, grid, dim3(64, 4), 0, st, frames, ny, nx, static_cast<double*>(ws));
+    hipLaunchKernelGGL(k_sobel_fin, dim3(batch), dim3(256), 0, st, static_cast<const double*>(ws), nblk, out);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+}  // extern "C"

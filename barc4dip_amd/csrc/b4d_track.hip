@@ -1,0 +1,579 @@
+// b4d_track.hip -- cross-correlation and phase-correlation translation tracking on gfx950
+// (reference signal/corr.py:169-253, signal/tracking.py:191-375).
+//
+// One 2-D forward transform per distinct image and per distinct template (K1 with ROI/z-score
+// sources + forward column pass), then per (image, template) pair:
+//   k_col_prod   Fi * conj(Ft) [/(|.| + eps) for phase correlation] fused into the inverse column FFT
+//   k_row_c2r    inverse row FFT -> real map (xcorr) or |map| + arg-max partials (tracking)
+//   k_track_fin  first-occurrence arg-max, exact median by 3-pass radix select, 3x3 Taylor step
+// Image spectra are computed once and reused by every template (the reference re-transforms
+// the same frame 18 times per time step, metrics/speckles.py:347-415).
+#include "b4d_fft2d.hpp"
+
+namespace b4d {
+
+// ------------------------------------------------------------------------------------ ROI statistics
+// grid (items), block 1024: population mean / std of the ROI in float64 (two passes over the ROI),
+// stored as float like NumPy's float32 arithmetic does: z = (x - f32(mean)) / f32(std + eps).
+__global__ void __launch_bounds__(1024) k_roi_stats(const float* __restrict__ frames, int ny, int nx, double eps,
+                                                    RowSrc* __restrict__ srcs) {
+    __shared__ double sh[16];
+    __shared__ double s_mean;
+    RowSrc sd = srcs[blockIdx.x];
+    const int h = sd.y1 - sd.y0, w = sd.x1 - sd.x0, n = h * w;
+    const float* f = frames + (size_t)sd.frame * ny * nx;
+    auto reduce = [&](double v) -> double {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double s = 0.0;
+        for (int i = 0; i < 16; ++i) s += sh[i];
+        return s;
+    };
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += (double)f[(size_t)(sd.y0 + i / w) * nx + sd.x0 + i % w];
+    const double mean = reduce(acc) / n;
+    if (threadIdx.x == 0) s_mean = mean;
+    __syncthreads();
+    acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double d = (double)f[(size_t)(sd.y0 + i / w) * nx + sd.x0 + i % w] - s_mean;
+        acc = fma(d, d, acc);
+    }
+    const double var = reduce(acc) / n;
+    if (threadIdx.x == 0) {
+        srcs[blockIdx.x].mean = (float)s_mean;
+        srcs[blockIdx.x].denom = (float)(sqrt(var) + eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------ product + inverse column pass
+struct ProdArgs {
+    const float2* spec_a;   // image half spectra (tile-major), item-indexed
+    const float2* nyq_a;    // (items, NY) Nyquist columns
+    const float2* spec_b;   // template half spectra
+    const float2* nyq_b;
+    const int* idx_a;       // per pair; null = identity
+    const int* idx_b;
+    float2* g;              // (pairs) tile-major output of the inverse column pass
+    const float2* tw;
+    float eps;
+    int nt;
+    unsigned flags;         // B4D_REMOVE_MEAN: zero the DC bin of the product (both means removed)
+};
+
+// c = a * conj(b), optionally whitened: c / (|c| + eps)   (signal/tracking.py:280-281)
+template <bool WHITEN>
+__device__ __forceinline__ float2 cross_power(float2 a, float2 b, float eps) {
+    float2 c = make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+    if (WHITEN) {
+        const float m = sqrtf(fmaf(c.x, c.x, c.y * c.y)) + eps;
+        c.x /= m;
+        c.y /= m;
+    }
+    return c;
+}
+
+// block CP*NY/16.  TILE0: grid (1, pairs) else (nt-1, pairs).
+template <int NY, int CP, bool TILE0, bool WHITEN>
+__global__ void __launch_bounds__(CP * (NY / E16)) k_col_prod(ProdArgs p) {
+    using G = ColGeom<NY, CP>;
+    constexpr int T = G::T, E = E16, CT = 2 * CP;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int cp = threadIdx.x % CP, u = threadIdx.x / CP;
+    const int ct = TILE0 ? 0 : blockIdx.x + 1, nt = p.nt;
+    const size_t pair = blockIdx.y;
+    const size_t ia = p.idx_a ? p.idx_a[pair] : pair, ib = p.idx_b ? p.idx_b[pair] : pair;
+    const float2* ta = p.spec_a + ((ia * nt + ct) * (size_t)NY) * CT;
+    const float2* tb = p.spec_b + ((ib * nt + ct) * (size_t)NY) * CT;
+    float2* tg = p.g + ((pair * nt + ct) * (size_t)NY) * CT;
+    const unsigned toff = (unsigned)u * CT + 2 * cp;
+    const bool packed = TILE0 && cp == 0;
+    float2 va[E], vb[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const float4 qa = *reinterpret_cast<const float4*>(ta + (size_t)(T * j * CT) + toff);
+        const float4 qb = *reinterpret_cast<const float4*>(tb + (size_t)(T * j * CT) + toff);
+        float2 c0 = cross_power<WHITEN>(make_float2(qa.x, qa.y), make_float2(qb.x, qb.y), p.eps);
+        const float2 c1 = cross_power<WHITEN>(make_float2(qa.z, qa.w), make_float2(qb.z, qb.w), p.eps);
+        if (packed) {  // column 0 also carries the Nyquist column: transform C0 + i*Cnyq in one go
+            const int ky = u + T * j;
+            const float2 cn = cross_power<WHITEN>(p.nyq_a[ia * NY + ky], p.nyq_b[ib * NY + ky], p.eps);
+            if (u == 0 && j == 0 && (p.flags & B4D_REMOVE_MEAN)) c0 = make_float2(0.f, 0.f);
+            c0 = make_float2(c0.x - cn.y, c0.y + cn.x);
+        }
+        va[j] = make_float2(c0.y, c0.x);  // (im, re)-swapped: inverse transform with the forward code
+        vb[j] = make_float2(c1.y, c1.x);
+    }
+    Fft3<G, 2>::run(va, vb, u, cp, lds, p.tw);
+#pragma unroll
+    for (int j = 0; j < E; ++j)
+        *reinterpret_cast<float4*>(tg + (size_t)(T * j * CT) + toff) = make_float4(va[j].y, va[j].x, vb[j].y, vb[j].x);
+}
+
+// ------------------------------------------------------------------------------------ tracking epilogue
+struct FinArgs {
+    const float* mag;       // (pairs, ny, nx)
+    const float* part_val;  // (pairs, nblk)
+    const int* part_idx;
+    double* out;            // (pairs, 4): dy, dx, peak, snr
+    int* peak_ij;           // (pairs, 2) or null
+    int ny, nx, nblk, subpixel;
+    double eps;
+};
+
+// Exact k-th smallest (0-based) of n non-negative floats by 3-pass radix select on the bit patterns
+// (11 + 11 + 10 bits).  Whole workgroup participates; result in every thread.  Also returns the number
+// of elements strictly below and equal to the selected value.
+__device__ unsigned radix_select(const float* __restrict__ x, unsigned n, unsigned k, unsigned* hist /*[2048]*/,
+                                 unsigned* sh /*[4]*/, unsigned& n_less, unsigned& n_equal) {
+    unsigned prefix = 0, mask = 0, below = 0;
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sft = shifts[pass], nb = 1 << widths[pass];
+        for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned key = __float_as_uint(x[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> sft) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // one wave: 32 bins per lane, then a wave scan
+            const int per = 2048 / 64;
+            unsigned s = 0;
+            for (int i = 0; i < per; ++i) s += hist[threadIdx.x * per + i];
+            unsigned incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o, 64);
+                if ((int)threadIdx.x >= o) incl += t;
+            }
+            const unsigned excl = incl - s, kk = k - below;
+            if (kk >= excl && kk < incl) {  // the bin is in this lane's range
+                unsigned run = excl;
+                for (int i = 0; i < per; ++i) {
+                    const unsigned c = hist[threadIdx.x * per + i];
+                    if (kk < run + c) {
+                        sh[0] = threadIdx.x * per + i;
+                        sh[1] = run;
+                        sh[2] = c;
+                        break;
+                    }
+                    run += c;
+                }
+            }
+        }
+        __syncthreads();
+        prefix |= sh[0] << sft;
+        mask |= (unsigned)(nb - 1) << sft;
+        below += sh[1];
+        n_equal = sh[2];
+        __syncthreads();
+    }
+    n_less = below;
+    return prefix;
+}
+
+// grid (pairs), block 1024
+__global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned sh[4];
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const size_t pair = blockIdx.x;
+    const unsigned n = (unsigned)p.ny * p.nx;
+    const float* mag = p.mag + pair * (size_t)n;
+    // ---- arg-max over the per-workgroup partials (first occurrence in row-major order)
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < p.nblk; i += blockDim.x)
+        argmax_merge(bv, bi, p.part_val[pair * p.nblk + i], p.part_idx[pair * p.nblk + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_down(bv, o, 64);
+        const int oi = __shfl_down(bi, o, 64);
+        argmax_merge(bv, bi, ov, oi);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sv[threadIdx.x >> 6] = bv;
+        si[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    bv = sv[0];
+    bi = si[0];
+    for (int i = 1; i < 16; ++i) argmax_merge(bv, bi, sv[i], si[i]);
+    __syncthreads();
+    // ---- median of the magnitude map (np.median: mean of the two middle values for even counts,
+    //      evaluated in float32 like NumPy does for a float32 array)
+    unsigned nl, ne;
+    float med;
+    if (n & 1u) {
+        med = __uint_as_float(radix_select(mag, n, n / 2, hist, sh, nl, ne));
+    } else {
+        const unsigned ka = radix_select(mag, n, n / 2 - 1, hist, sh, nl, ne);
+        float a = __uint_as_float(ka), b = a;
+        if (nl + ne <= n / 2) {  // the upper middle value is the next larger element
+            unsigned best = 0x7f800000u;
+            for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+                const unsigned key = __float_as_uint(mag[i]);
+                if (key > ka && key < best) best = key;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned t = __shfl_down(best, o, 64);
+                best = t < best ? t : best;
+            }
+            if ((threadIdx.x & 63) == 0) hist[threadIdx.x >> 6] = best;
+            __syncthreads();
+            best = hist[0];
+            for (int i = 1; i < 16; ++i) best = hist[i] < best ? hist[i] : best;
+            b = __uint_as_float(best);
+        }
+        med = __fmul_rn(__fadd_rn(a, b), 0.5f);
+    }
+    if (threadIdx.x != 0) return;
+    // ---- peak quality + Taylor step, op for op like tracking.py:314-375 (float32 scalars, no contraction)
+    const int mi = bi / p.nx, mj = bi % p.nx;
+    const double peak = (double)bv;
+    const double snr = fabs(peak) / ((double)med + p.eps);
+    double dy = (double)(mi - p.ny / 2), dx = (double)(mj - p.nx / 2);
+    if (p.subpixel && mi > 0 && mi < p.ny - 1 && mj > 0 && mj < p.nx - 1) {
+        auto c = [&](int di, int dj) { return mag[(size_t)(mi + di) * p.nx + (mj + dj)]; };
+        const float c00 = c(0, 0);
+        const float gy = __fdiv_rn(__fsub_rn(c(1, 0), c(-1, 0)), 2.0f);
+        const float hyy = __fsub_rn(__fadd_rn(c(1, 0), c(-1, 0)), __fmul_rn(2.0f, c00));
+        const float gx = __fdiv_rn(__fsub_rn(c(0, 1), c(0, -1)), 2.0f);
+        const float hxx = __fsub_rn(__fadd_rn(c(0, 1), c(0, -1)), __fmul_rn(2.0f, c00));
+        const float hxy = __fdiv_rn(__fadd_rn(__fsub_rn(__fsub_rn(c(1, 1), c(1, -1)), c(-1, 1)), c(-1, -1)), 4.0f);
+        const float det = __fsub_rn(__fmul_rn(hxx, hyy), __fmul_rn(hxy, hxy));
+        if (det != 0.0f) {
+            const float inv = __fdiv_rn(1.0f, det);
+            // NOTE the reference's swapped corrections (tracking.py:372-373), reproduced on purpose
+            const float di = __fmul_rn(-__fsub_rn(__fmul_rn(hyy, gx), __fmul_rn(hxy, gy)), inv);
+            const float dj = __fmul_rn(-__fsub_rn(__fmul_rn(hxx, gy), __fmul_rn(hxy, gx)), inv);
+            dy += (double)di;
+            dx += (double)dj;
+        }
+    }
+    double* o = p.out + pair * 4;
+    o[0] = dy;
+    o[1] = dx;
+    o[2] = peak;
+    o[3] = snr;
+    if (p.peak_ij) {
+        p.peak_ij[pair * 2] = mi;
+        p.peak_ij[pair * 2 + 1] = mj;
+    }
+}
+
+// ------------------------------------------------------------------------------------ |max| normalisation (xcorr2d, normalize="peak")
+__global__ void __launch_bounds__(1024) k_absmax_part(const float* __restrict__ x, size_t n, float* __restrict__ part) {
+    __shared__ float sh[16];
+    const float* f = x + (size_t)blockIdx.y * n;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(f[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, sh[i]);
+        part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    }
+}
+__global__ void __launch_bounds__(256) k_scale_by_max(float* __restrict__ x, size_t n, const float* __restrict__ part,
+                                                      int nparts) {
+    __shared__ float s_inv;
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int i = 0; i < nparts; ++i) m = fmaxf(m, part[(size_t)blockIdx.y * nparts + i]);
+        s_inv = m > 0.f ? m : 1.f;
+    }
+    __syncthreads();
+    float* f = x + (size_t)blockIdx.y * n;
+    const float m = s_inv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) f[i] = f[i] / m;
+}
+
+}  // namespace b4d
+
+using namespace b4d;
+
+// ===================================================================================== host
+template <int NY, int CP, bool TILE0, bool WHITEN>
+static int launch_prod1(const ProdArgs& a, int gx, int pairs, hipStream_t st) {
+    using G = ColGeom<NY, CP>;
+    const size_t lds = sizeof(float2) * (size_t)G::LDS_ELEMS * CP;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col_prod<NY, CP, TILE0, WHITEN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    B4D_HIP(attr_err);
+    if (gx < 1) return B4D_OK;
+    hipLaunchKernelGGL((k_col_prod<NY, CP, TILE0, WHITEN>), dim3(gx, pairs), dim3(CP * (NY / E16)), lds, st, a);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+template <bool WHITEN>
+static int dispatch_prod(const b4d_plan* pl, ProdArgs a, int pairs, hipStream_t st) {
+    const int nt = (pl->nx / 2) / pl->ct_w;
+    a.nt = nt;
+    int rc = B4D_OK;
+#define B4D_PROD_CASE(NY, CP)                                                     \
+    case NY:                                                                      \
+        rc = launch_prod1<NY, CP, false, WHITEN>(a, nt - 1, pairs, st);           \
+        if (rc == B4D_OK) rc = launch_prod1<NY, CP, true, WHITEN>(a, 1, pairs, st); \
+        return rc;
+    switch (pl->ny) {
+        B4D_PROD_CASE(64, 8)
+        B4D_PROD_CASE(128, 8)
+        B4D_PROD_CASE(256, 8)
+        B4D_PROD_CASE(512, 8)
+        B4D_PROD_CASE(1024, 8)
+        B4D_PROD_CASE(2048, 8)
+        B4D_PROD_CASE(4096, 4)
+    }
+#undef B4D_PROD_CASE
+    return fail(B4D_ESIZE, "unsupported ny");
+}
+
+template <int NX>
+static int launch_c2r_mode(const b4d_plan* pl, const RowOutArgs& a, int batch, bool mag, hipStream_t st, int* nblk) {
+    constexpr int SEQ = row_seq(NX);
+    const dim3 grid((pl->ny / 2 + SEQ - 1) / SEQ, batch), block((NX / E16) * SEQ);
+    if (nblk) *nblk = grid.x;
+    if (batch < 1) return B4D_OK;
+    if (mag)
+        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_MAG>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_OUT>), grid, block, 0, st, a);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+static int dispatch_c2r_mode(const b4d_plan* pl, const RowOutArgs& a, int batch, bool mag, hipStream_t st, int* nblk) {
+    switch (pl->nx) {
+        case 64: return launch_c2r_mode<64>(pl, a, batch, mag, st, nblk);
+        case 128: return launch_c2r_mode<128>(pl, a, batch, mag, st, nblk);
+        case 256: return launch_c2r_mode<256>(pl, a, batch, mag, st, nblk);
+        case 512: return launch_c2r_mode<512>(pl, a, batch, mag, st, nblk);
+        case 1024: return launch_c2r_mode<1024>(pl, a, batch, mag, st, nblk);
+        case 2048: return launch_c2r_mode<2048>(pl, a, batch, mag, st, nblk);
+        case 4096: return launch_c2r_mode<4096>(pl, a, batch, mag, st, nblk);
+    }
+    return fail(B4D_ESIZE, "unsupported nx");
+}
+
+// forward 2-D half spectra of `items` sources into spec (tile-major) + nyq (items, ny)
+static int forward_spectra(const b4d_plan* pl, const float* frames, const RowSrc* srcs, int items, float2* spec,
+                           float2* nyq, hipStream_t st) {
+    int rc = dispatch_r2c(pl, frames, items, st, spec, srcs);
+    if (rc) return rc;
+    ColArgs ca{};
+    ca.spec = spec;
+    ca.full = nyq;
+    ca.tw = pl->tw_y;
+    ca.nx = pl->nx;
+    return dispatch_col<COL_FORWARD>(pl, ca, items, st);
+}
+
+namespace {
+// byte-carving helper over one hipMalloc'ed arena
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0, cap = 0;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+}  // namespace
+
+static int track_arena(b4d_plan* pl, size_t bytes, Arena* a) {
+    if (bytes > pl->track_bytes) {
+        if (pl->track_ws) (void)hipFree(pl->track_ws);
+        pl->track_ws = nullptr;
+        pl->track_bytes = 0;
+        hipError_t e = hipMalloc(&pl->track_ws, bytes);
+        if (e != hipSuccess) return fail(B4D_ENOMEM, std::string("tracking workspace: ") + hipGetErrorString(e));
+        pl->track_bytes = bytes;
+    }
+    a->base = static_cast<char*>(pl->track_ws);
+    a->off = 0;
+    a->cap = pl->track_bytes;
+    return B4D_OK;
+}
+
+extern "C" {
+
+int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, void* stream) {
+    if (!pl || !a || !b || !corr) return fail(B4D_EINVAL, "null argument");
+    if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t fpix = (size_t)pl->ny * pl->nx, half = fpix / 2;
+    const int chunk = pl->chunk;
+    Arena ar;
+    const size_t need = 3 * (sizeof(float2) * half * chunk + 256) + 2 * (sizeof(float2) * pl->ny * chunk + 256) +
+                        2 * sizeof(RowSrc) * chunk + 512 + sizeof(float) * 256 * chunk + 256;
+    int rc = track_arena(pl, need, &ar);
+    if (rc) return rc;
+    float2* sa = ar.take<float2>(half * chunk);
+    float2* sb = ar.take<float2>(half * chunk);
+    float2* g = ar.take<float2>(half * chunk);
+    float2* na = ar.take<float2>((size_t)pl->ny * chunk);
+    float2* nb_ = ar.take<float2>((size_t)pl->ny * chunk);
+    float* part = ar.take<float>((size_t)256 * chunk);
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = std::min(chunk, batch - b0);
+        if ((rc = forward_spectra(pl, a + b0 * fpix, nullptr, nb, sa, na, st))) return rc;
+        if ((rc = forward_spectra(pl, b + b0 * fpix, nullptr, nb, sb, nb_, st))) return rc;
+        ProdArgs pa{};
+        pa.spec_a = sa;
+        pa.nyq_a = na;
+        pa.spec_b = sb;
+        pa.nyq_b = nb_;
+        pa.g = g;
+        pa.tw = pl->tw_y;
+        pa.eps = 0.f;
+        pa.flags = flags;
+        if ((rc = dispatch_prod<false>(pl, pa, nb, st))) return rc;
+        RowOutArgs ra{};
+        ra.g = g;
+        ra.out = corr + b0 * fpix;
+        ra.tw = pl->tw_x;
+        ra.scale = 1.0f / ((float)pl->nx * (float)pl->ny);
+        ra.ny = pl->ny;
+        ra.ct_w = pl->ct_w;
+        ra.flags = 0;
+        if ((rc = dispatch_c2r_mode(pl, ra, nb, false, st, nullptr))) return rc;
+        if (flags & B4D_NORM_PEAK) {
+            hipLaunchKernelGGL(k_absmax_part, dim3(256, nb), dim3(1024), 0, st, corr + b0 * fpix, fpix, part);
+            hipLaunchKernelGGL(k_scale_by_max, dim3(1024, nb), dim3(256), 0, st, corr + b0 * fpix, fpix, part, 256);
+            B4D_HIP(hipGetLastError());
+        }
+    }
+    return B4D_OK;
+}
+
+int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const float* tpl_src, int ntplsrc,
+                          const int32_t* tpl_frame, const int32_t* tpl_roi, int ntpl, const int32_t* pair_img,
+                          const int32_t* pair_tpl, int npairs, int subpixel, double eps, double* out, int32_t* peak_ij,
+                          void* stream) {
+    if (!pl || !images || !tpl_src || !tpl_frame || !tpl_roi || !pair_img || !pair_tpl || !out)
+        return fail(B4D_EINVAL, "null argument");
+    if (nimg < 1 || ntplsrc < 1 || ntpl < 1 || npairs < 1) return fail(B4D_EINVAL, "counts must be >= 1");
+    const int ny = pl->ny, nx = pl->nx;
+    for (int k = 0; k < ntpl; ++k) {
+        const int32_t* r = tpl_roi + 4 * k;
+        if (tpl_frame[k] < 0 || tpl_frame[k] >= ntplsrc || r[0] < 0 || r[1] > ny || r[0] >= r[1] || r[2] < 0 || r[3] > nx ||
+            r[2] >= r[3])
+            return fail(B4D_EINVAL, "template " + std::to_string(k) + ": frame or ROI out of range");
+    }
+    for (int i = 0; i < npairs; ++i)
+        if (pair_img[i] < 0 || pair_img[i] >= nimg || pair_tpl[i] < 0 || pair_tpl[i] >= ntpl)
+            return fail(B4D_EINVAL, "pair " + std::to_string(i) + ": index out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t fpix = (size_t)ny * nx, half = fpix / 2;
+    const int pc = std::max(1, std::min(npairs, pl->chunk * 4));  // pairs per launch group
+    const int nsrc = nimg + ntpl;
+    size_t need = 0;
+    auto add = [&](size_t b) { need += ((b + 255) & ~(size_t)255) + 256; };
+    add(sizeof(float2) * half * nsrc);        // spectra
+    add(sizeof(float2) * (size_t)ny * nsrc);  // nyquist columns
+    add(sizeof(RowSrc) * nsrc);
+    add(sizeof(int) * 2 * (size_t)npairs);
+    add(sizeof(float2) * half * pc);          // G
+    add(sizeof(float) * fpix * pc);           // magnitude maps
+    add(sizeof(float) * 2048 * (size_t)pc);
+    add(sizeof(int) * 2048 * (size_t)pc);
+    Arena ar;
+    int rc = track_arena(pl, need, &ar);
+    if (rc) return rc;
+    float2* spec = ar.take<float2>(half * nsrc);
+    float2* nyq = ar.take<float2>((size_t)ny * nsrc);
+    RowSrc* srcs = ar.take<RowSrc>(nsrc);
+    int* pidx = ar.take<int>(2 * (size_t)npairs);
+    float2* g = ar.take<float2>(half * pc);
+    float* mag = ar.take<float>(fpix * pc);
+    float* pval = ar.take<float>((size_t)2048 * pc);
+    int* pind = ar.take<int>((size_t)2048 * pc);
+
+    // ---- source descriptors: images (full frame, z-scored), then templates (ROI, z-scored, zero elsewhere)
+    std::vector<RowSrc> h(nsrc);
+    for (int i = 0; i < nimg; ++i) h[i] = RowSrc{i, 0, ny, 0, nx, 0.f, 1.f, 0};
+    for (int k = 0; k < ntpl; ++k)
+        h[nimg + k] = RowSrc{tpl_frame[k], tpl_roi[4 * k], tpl_roi[4 * k + 1], tpl_roi[4 * k + 2], tpl_roi[4 * k + 3], 0.f, 1.f, 0};
+    std::vector<int> hp(2 * (size_t)npairs);
+    for (int i = 0; i < npairs; ++i) {
+        hp[i] = pair_img[i];
+        hp[npairs + i] = nimg + pair_tpl[i];
+    }
+    B4D_HIP(hipMemcpyAsync(srcs, h.data(), sizeof(RowSrc) * nsrc, hipMemcpyHostToDevice, st));
+    B4D_HIP(hipMemcpyAsync(pidx, hp.data(), sizeof(int) * hp.size(), hipMemcpyHostToDevice, st));
+    B4D_HIP(hipStreamSynchronize(st));  // h / hp are stack-owned
+    hipLaunchKernelGGL(k_roi_stats, dim3(nimg), dim3(1024), 0, st, images, ny, nx, eps, srcs);
+    hipLaunchKernelGGL(k_roi_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, eps, srcs + nimg);
+    B4D_HIP(hipGetLastError());
+    // ---- spectra (once per distinct image / template)
+    const int fc = std::max(1, pl->chunk * 2);
+    for (int i0 = 0; i0 < nimg; i0 += fc) {
+        const int n = std::min(fc, nimg - i0);
+        if ((rc = forward_spectra(pl, images, srcs + i0, n, spec + half * i0, nyq + (size_t)ny * i0, st))) return rc;
+    }
+    for (int k0 = 0; k0 < ntpl; k0 += fc) {
+        const int n = std::min(fc, ntpl - k0);
+        if ((rc = forward_spectra(pl, tpl_src, srcs + nimg + k0, n, spec + half * (nimg + k0),
+                                  nyq + (size_t)ny * (nimg + k0), st)))
+            return rc;
+    }
+    // ---- pairs
+    for (int p0 = 0; p0 < npairs; p0 += pc) {
+        const int np = std::min(pc, npairs - p0);
+        ProdArgs pa{};
+        pa.spec_a = spec;
+        pa.nyq_a = nyq;
+        pa.spec_b = spec;
+        pa.nyq_b = nyq;
+        pa.idx_a = pidx + p0;
+        pa.idx_b = pidx + npairs + p0;
+        pa.g = g;
+        pa.tw = pl->tw_y;
+        pa.eps = (float)eps;
+        if ((rc = dispatch_prod<true>(pl, pa, np, st))) return rc;
+        RowOutArgs ra{};
+        ra.g = g;
+        ra.out = mag;
+        ra.tw = pl->tw_x;
+        ra.scale = 1.0f / ((float)nx * (float)ny);
+        ra.ny = ny;
+        ra.ct_w = pl->ct_w;
+        ra.part_val = pval;
+        ra.part_idx = pind;
+        int nblk = 0;
+        if ((rc = dispatch_c2r_mode(pl, ra, np, true, st, &nblk))) return rc;
+        FinArgs fa{};
+        fa.mag = mag;
+        fa.part_val = pval;
+        fa.part_idx = pind;
+        fa.out = out + (size_t)p0 * 4;
+        fa.peak_ij = peak_ij ? peak_ij + (size_t)p0 * 2 : nullptr;
+        fa.ny = ny;
+        fa.nx = nx;
+        fa.nblk = nblk;
+        fa.subpixel = subpixel;
+        fa.eps = eps;
+        hipLaunchKernelGGL(k_track_fin, dim3(np), dim3(1024), 0, st, fa);
+        B4D_HIP(hipGetLastError());
+    }
+    return B4D_OK;
+}
+
+}  // extern "C"

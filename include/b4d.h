@@ -42,7 +42,7 @@ typedef struct b4d_plan b4d_plan;
 /* Library / device ------------------------------------------------------------------- */
 const char* b4d_version(void);
 const char* b4d_last_error(void);
-/* 1 if (ny, nx) has a native (power-of-two) plan: ny, nx in {512, 1024, 2048, 4096}. */
+/* 1 if (ny, nx) has a native plan: ny, nx powers of two in [64, 4096]. */
 int b4d_size_supported(int ny, int nx);
 
 /* Plans ------------------------------------------------------------------------------
@@ -71,21 +71,33 @@ int b4d_autocorr2d(b4d_plan* plan, const float* frames, int batch, float* autoco
 int b4d_psd_autocorr2d(b4d_plan* plan, const float* frames, int batch, float* psd, float psd_scale,
                        float* autocorr, unsigned flags, void* stream);
 
+/* Same call, but every kernel launch is bracketed by HIP events on `stream`; the elapsed times
+ * (ms) of {row R2C, column FFT/PSD/inverse, zero-lag peak, row C2R} are ADDED to kernel_ms[0..3].
+ * Synchronises the stream before returning.  Measurement aid for bench.py's roofline block.    */
+int b4d_psd_autocorr2d_timed(b4d_plan* plan, const float* frames, int batch, float* psd, float psd_scale,
+                             float* autocorr, unsigned flags, void* stream, float* kernel_ms);
+
 /* signal/corr.py:169-253 xcorr2d -- fftshift(ifft2(fft2(a) * conj(fft2(b)))), real part,
- * float32.  flags as above (B4D_NORM_PEAK divides by max|corr|).                        */
+ * float32, scaled 1/(nx*ny) like ifft2.  B4D_REMOVE_MEAN zeroes the DC bin of the cross
+ * spectrum (= both means removed), B4D_NORM_PEAK divides by max|corr|.                   */
 int b4d_xcorr2d(b4d_plan* plan, const float* a, const float* b, int batch, float* corr, unsigned flags,
                 void* stream);
 
-/* signal/tracking.py:191-297 phase_correlation (backend="internal") for `npairs`
- * (image, template) pairs.  images: (nimg, ny, nx) raw frames; templates are cut from
- * `tpl_src` frames: pair i uses image img_idx[i], template frame tpl_idx[i] and the ROI
- * roi[i] = {y0, y1, x0, x1}.  z-scoring (tracking.py:308-311), zero-embedding
- * (geometry/roi.py:175-222), whitening, |ifft2|, first-occurrence arg-max, peak, median
- * SNR and the 3x3 Taylor step all run on the device.
- * out: (npairs, 4) float64 rows {dy, dx, peak, snr}; peak_ij: (npairs, 2) int32 or NULL. */
-int b4d_phase_correlation(b4d_plan* plan, const float* images, int nimg, const float* tpl_src, int ntpl,
-                          const int32_t* img_idx, const int32_t* tpl_idx, const int32_t* roi, int npairs,
-                          int subpixel, double eps, double* out, int32_t* peak_ij, void* stream);
+/* signal/tracking.py:191-297 phase_correlation (backend="internal") for `npairs` (image,
+ * template) pairs.  images: (nimg, ny, nx) raw frames.  Templates are ROIs of the frames in
+ * tpl_src (ntplsrc, ny, nx): template k = frame tpl_frame[k], rows [roi[4k], roi[4k+1]),
+ * columns [roi[4k+2], roi[4k+3]).  Pair i correlates image pair_img[i] with template
+ * pair_tpl[i].  Every distinct image and template is transformed ONCE.  z-scoring
+ * (tracking.py:308-311), zero-embedding (geometry/roi.py:175-222), whitening, |ifft2|,
+ * first-occurrence arg-max, peak, exact median for the SNR (tracking.py:314-321) and the 3x3
+ * Taylor step (324-375, including its swapped corrections) all run on the device.
+ * The index arrays (tpl_frame, tpl_roi, pair_img, pair_tpl) are HOST pointers; out
+ * (npairs, 4) float64 rows {dy, dx, peak, snr} and peak_ij (npairs, 2) int32 (nullable) are
+ * DEVICE pointers.                                                                        */
+int b4d_phase_correlation(b4d_plan* plan, const float* images, int nimg, const float* tpl_src, int ntplsrc,
+                          const int32_t* tpl_frame, const int32_t* tpl_roi, int ntpl, const int32_t* pair_img,
+                          const int32_t* pair_tpl, int npairs, int subpixel, double eps, double* out,
+                          int32_t* peak_ij, void* stream);
 
 /* Temporal per-pixel statistics (io/rw.py:129-132 for the mean).
  * accumulate: sum_x += sum_t x, sum_xx += sum_t x^2 over `nframes` frames of npix pixels

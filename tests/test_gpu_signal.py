@@ -1,0 +1,202 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against the NumPy oracle.
+
+Tolerances (stated per SURVEY.md §8d): FFT/PSD/autocorrelation values are float32 on the device
+and are compared NORMWISE with the float64 oracle: max|got-ref| <= 1e-5 * max|ref|.  Index
+outputs (arg-max of the autocorrelation) are exact, and the peak value is exactly 1.0.
+"""
+import numpy as np
+import pytest
+
+from barc4dip_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def nerr(got, ref):
+    return float(np.max(np.abs(np.asarray(got) - ref)) / np.max(np.abs(ref)))
+
+
+@pytest.fixture(scope="module")
+def gs():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from barc4dip_amd import _ffi, signal
+
+    lib = _ffi.load_library()
+    assert lib.b4d_missing_symbols == ()
+    return signal
+
+
+def frame(ny, nx, seed=1234, dtype=np.float32):
+    n = max(ny, nx)
+    return np.ascontiguousarray(synth.speckle_frame(n, seed)[:ny, :nx]).astype(dtype)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (128, 256), (256, 64), (512, 512), (1024, 512), (512, 2048), (2048, 2048),
+                                   (4096, 1024)])
+def test_fft_psd_autocorr_vs_oracle(gs, shape):
+    from oracle import signal_np as S
+
+    img = frame(*shape)
+    ref64 = img.astype(np.float64)
+    F, fx, fy = gs.fft2d(img, dx=0.5, dy=2.0)
+    Fr, fxr, fyr = S.fft2d(ref64, dx=0.5, dy=2.0)
+    assert F.shape == shape and F.dtype == np.complex64
+    assert nerr(F, Fr) < TOL
+    np.testing.assert_array_equal(fx, fxr)
+    np.testing.assert_array_equal(fy, fyr)
+    # error of the reference's own float32 path, for the record: ours must not be worse than 4x that
+    e32 = nerr(S.fft2d(img)[0], Fr)
+    assert nerr(F, Fr) <= max(4 * e32, 2e-7)
+
+    for kw in ({}, dict(dx=0.5, dy=2.0), dict(scale=False)):
+        P = gs.psd2d(img, **kw)[0]
+        Pr = S.psd2d(ref64, **kw)[0]
+        assert P.dtype == np.float32
+        assert nerr(P, Pr) < TOL
+        cy, cx = shape[0] // 2, shape[1] // 2
+        Pm, Prm = P.astype(np.float64), Pr.copy()
+        Pm[cy, cx] = Prm[cy, cx] = 0.0       # without the DC bin the bound is much tighter in l2
+        assert np.linalg.norm(Pm - Prm) / np.linalg.norm(Prm) < TOL
+
+    ac, xl, yl = gs.autocorr2d(img)
+    acr, xlr, ylr = S.autocorr2d(ref64)
+    assert ac.dtype == np.float64 and ac.shape == shape
+    assert float(np.max(np.abs(ac - acr))) < TOL           # max|ref| == 1
+    assert np.unravel_index(int(np.argmax(ac)), ac.shape) == (shape[0] // 2, shape[1] // 2)
+    assert ac[shape[0] // 2, shape[1] // 2] == 1.0
+    np.testing.assert_array_equal(xl, xlr)
+    np.testing.assert_array_equal(yl, ylr)
+
+
+@pytest.mark.parametrize("rm", [True, False])
+@pytest.mark.parametrize("st", [True, False])
+@pytest.mark.parametrize("nm", ["peak", "none"])
+def test_autocorr_options(gs, rm, st, nm):
+    from oracle import signal_np as S
+
+    img = frame(512, 1024, seed=7)
+    got = gs.autocorr2d(img, remove_mean=rm, standardize=st, normalize=nm)[0]
+    ref = S.autocorr2d(img.astype(np.float64), remove_mean=rm, standardize=st, normalize=nm)[0]
+    assert nerr(got, ref) < TOL
+
+
+def test_float64_input_and_calibrated_axes(gs):
+    from oracle import signal_np as S
+
+    img = frame(512, 512, seed=3, dtype=np.float64)
+    x = np.linspace(0.0, 51.1, 512)
+    y = np.linspace(10.0, 10.0 + 2 * 511, 512)
+    P, fx, fy = gs.psd2d(img, x=x, y=y)
+    Pr, fxr, fyr = S.psd2d(img, x=x, y=y)
+    assert P.dtype == np.float64
+    assert nerr(P, Pr) < TOL
+    np.testing.assert_array_equal(fx, fxr)
+    np.testing.assert_array_equal(fy, fyr)
+    F = gs.fft2d(img)[0]
+    assert F.dtype == np.complex128 and nerr(F, S.fft2d(img)[0]) < TOL
+
+
+def test_errors(gs):
+    with pytest.raises(ValueError):
+        gs.fft2d(np.zeros(16, dtype=np.float32))
+    with pytest.raises(ValueError):
+        gs.psd2d(np.zeros((512, 512), dtype=np.float32), x=np.arange(512.0))
+    with pytest.raises(ValueError):
+        gs.psd2d(np.zeros((512, 512), dtype=np.float32), dx=-1.0)
+    with pytest.raises(ValueError):
+        gs.autocorr2d(np.zeros((512, 512), dtype=np.float32), normalize="bogus")
+    with pytest.raises(ValueError):
+        gs.autocorr2d(np.zeros((4, 512, 512), dtype=np.float32))
+    with pytest.raises(NotImplementedError):           # no CPU fallback for sizes without a native plan
+        gs.psd2d(np.zeros((100, 100), dtype=np.float32))
+    with pytest.raises(NotImplementedError):
+        gs.autocorr2d(np.zeros((32, 64), dtype=np.float32))
+    with pytest.raises(NotImplementedError):
+        gs.fft2d(np.zeros((512, 512), dtype=np.complex64))
+
+
+def test_stack_equals_frames_and_chunking(gs):
+    import torch
+
+    from barc4dip_amd import _ffi
+    import ctypes as C
+
+    stack = synth.speckle_stack(5, 512, seed0=50)
+    psd, ac = gs.psd_autocorr2d_stack(stack)
+    for t in range(5):
+        np.testing.assert_array_equal(psd[t], gs.psd2d(stack[t])[0])
+        np.testing.assert_array_equal(ac[t], gs.autocorr2d(stack[t])[0].astype(np.float32))
+    # chunk size must not change a single bit (ragged last chunk included)
+    dev = torch.from_numpy(stack).cuda()
+    outs = []
+    for chunk in (1, 2, 5, 8):
+        pl = _ffi.Plan(512, 512, chunk)
+        p = torch.empty_like(dev)
+        a = torch.empty_like(dev)
+        _ffi.check(_ffi.lib().b4d_psd_autocorr2d(pl.handle, C.c_void_p(dev.data_ptr()), 5, C.c_void_p(p.data_ptr()),
+                                                 1.0, C.c_void_p(a.data_ptr()), 3, _ffi.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((p.cpu().numpy(), a.cpu().numpy()))
+        pl.close()
+    for p, a in outs[1:]:
+        np.testing.assert_array_equal(p, outs[0][0])
+        np.testing.assert_array_equal(a, outs[0][1])
+
+
+def test_full_size_properties(gs):
+    """Size-independent properties at the benchmark size (2048^2, 8-frame stack)."""
+    import torch
+
+    T, n = 8, 2048
+    dev = synth.speckle_stack_device(T, n, seed0=99)
+    psd, ac = gs.psd_autocorr2d_stack(dev, scale=False, return_tensors=True)
+    x = dev.double()
+    # Parseval: sum |F|^2 = N^2 * sum x^2
+    lhs = psd.double().sum(dim=(1, 2))
+    rhs = (x * x).sum(dim=(1, 2)) * (n * n)
+    assert float(((lhs - rhs).abs() / rhs).max()) < 1e-6
+    # DC bin = (sum x)^2
+    dc = psd[:, n // 2, n // 2].double()
+    assert float(((dc - x.sum(dim=(1, 2)) ** 2).abs() / dc).max()) < 1e-6
+    # Hermitian symmetry of the PSD and evenness of the autocorrelation: out[-k] == out[k]
+    def mirror(a):
+        return torch.roll(torch.flip(a, dims=(1, 2)), shifts=(1, 1), dims=(1, 2))
+    assert torch.equal(mirror(psd)[:, 1:, 1:], psd[:, 1:, 1:])
+    assert float((mirror(ac) - ac).abs().max()) < 2e-6
+    # peak: exactly one, at the centre, strictly the maximum
+    assert torch.all(ac[:, n // 2, n // 2] == 1.0)
+    flat = ac.reshape(T, -1)
+    assert torch.all(flat.argmax(dim=1) == (n // 2) * n + n // 2)
+    # mean removal: the autocorrelation sums to ~0 (DC bin zeroed)
+    assert float(ac.double().sum(dim=(1, 2)).abs().max()) < 1e-2 * n
+    # circular shift invariance of PSD and autocorrelation
+    sh = torch.roll(dev, shifts=(37, -501), dims=(1, 2))
+    psd2, ac2 = gs.psd_autocorr2d_stack(sh, scale=False, return_tensors=True)
+    assert float(((psd2 - psd).abs().amax(dim=(1, 2)) / psd.amax(dim=(1, 2))).max()) < 1e-6
+    assert float((ac2 - ac).abs().max()) < 1e-5
+    # linearity of fft2d
+    F1 = gs.fft2d_stack(dev[:1], return_tensors=True)
+    F2 = gs.fft2d_stack(dev[1:2], return_tensors=True)
+    F12 = gs.fft2d_stack(dev[:1] * 2 - dev[1:2], return_tensors=True)
+    assert float(((F12 - (2 * F1 - F2)).abs().max() / F12.abs().max())) < 1e-6
+    # ifft2d(fft2d(x)) ~ x (host inverse)
+    xr = gs.fft.ifft2d(F1[0].cpu().numpy())
+    assert float(np.max(np.abs(xr.real - dev[0].cpu().numpy())) / float(dev[0].max())) < 1e-5
+
+
+def test_golden_reference_vectors_64(gs, golden):
+    """Committed outputs of the REAL reference (tests/golden/signal_small.npz, f32_64 case)."""
+    g = golden("signal_small.npz")
+    a, b = g["f32_64/a"], g["f32_64/b"]
+    assert nerr(gs.fft2d(a, dx=0.5, dy=2.0)[0], g["f32_64/fft2d"]) < TOL
+    assert nerr(gs.psd2d(a)[0], g["f32_64/psd2d"]) < TOL
+    assert nerr(gs.psd2d(a, dx=0.5, dy=2.0)[0], g["f32_64/psd2d_cal"]) < TOL
+    assert nerr(gs.psd2d(a, scale=False)[0], g["f32_64/psd2d_noscale"]) < TOL
+    assert nerr(gs.autocorr2d(a)[0], g["f32_64/autocorr2d_rm1_st0_peak"]) < TOL
+    assert nerr(gs.autocorr2d(a, standardize=True, normalize="none")[0], g["f32_64/autocorr2d_rm1_st1_none"]) < TOL
+    assert nerr(gs.xcorr2d(a, b)[0], np.real(g["f32_64/xcorr2d_rm1_st0_peak"])) < TOL
+    assert nerr(gs.xcorr2d(a, b, standardize=True, normalize="none")[0], np.real(g["f32_64/xcorr2d_rm1_st1_none"])) < TOL

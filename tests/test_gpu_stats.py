@@ -1,0 +1,72 @@
+"""GPU tier: reduction kernels (moments, Sobel/Laplace, temporal sums) vs the oracle."""
+import numpy as np
+import pytest
+
+from barc4dip_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    import torch
+
+    assert torch.cuda.is_available()
+    from barc4dip_amd.metrics import kernels
+
+    return kernels
+
+
+def test_moments_vs_oracle(K):
+    from oracle import metrics_np as M
+
+    frames = np.stack([synth.speckle_frame(512, 5)[:500, :404], synth.speckle_frame(512, 6)[:500, :404] * 60.0])
+    frames[1, 3, 7] = np.nan
+    frames[1, 100, 9] = np.inf
+    frames[0, :4, :4] = 0.0
+    out = K.moments_batch(frames, eps=1e-6, saturation=3000.0).cpu().numpy()
+    for b in range(2):
+        ref = M.distribution_moments(frames[b], saturation_value=3000.0)
+        n, mean, m2, m3, m4, nz, ns = out[b, :7]
+        assert n == np.isfinite(frames[b]).sum()
+        assert mean == pytest.approx(ref["mean"], rel=1e-12)
+        var = m2 / n
+        assert np.sqrt(var) == pytest.approx(ref["std"], rel=1e-12)
+        assert (m3 / n) / var ** 1.5 == pytest.approx(ref["skewness"], rel=1e-10)
+        assert (m4 / n) / var ** 2 - 3.0 == pytest.approx(ref["kurtosis"], rel=1e-10)
+        assert nz / n == ref["frac_zero"] and ns / n == ref["frac_sat"]
+
+
+@pytest.mark.parametrize("shape", [(171, 170), (512, 512), (64, 700)])
+def test_sobel_laplace_vs_oracle(K, shape):
+    from oracle import metrics_np as M
+
+    frames = np.stack([synth.speckle_frame(1024, 9)[:shape[0], :shape[1]], synth.speckle_frame(1024, 10)[:shape[0], :shape[1]]])
+    out = K.sobel_laplace_batch(frames).cpu().numpy()
+    for b in range(2):
+        t = M.tenengrad(frames[b])
+        assert out[b, 0] == pytest.approx(t["ex"], rel=1e-12)
+        assert out[b, 1] == pytest.approx(t["ey"], rel=1e-12)
+        lv = M.laplacian_variance(frames[b])
+        assert out[b, 3] - out[b, 2] ** 2 == pytest.approx(lv, rel=1e-10)
+
+
+def test_temporal_stats_vs_oracle():
+    from barc4dip_amd.metrics import temporal_stats
+    from oracle import temporal_np as Tn
+
+    stack = synth.speckle_stack(64, 256, seed0=300)          # the cfg4 parity case: (64, 256, 256)
+    mean, var, con = temporal_stats(stack, chunk=24)         # ragged chunks on purpose
+    rm, rv, rc = Tn.temporal_stats(stack)
+    np.testing.assert_allclose(mean, rm, rtol=2e-7)
+    np.testing.assert_allclose(var, rv, rtol=2e-6)
+    np.testing.assert_allclose(con, rc, rtol=2e-6)
+    # exactness of the float64 sums: integers (Poisson counts) sum exactly
+    import torch
+    from barc4dip_amd.metrics import kernels as K
+
+    dev = torch.from_numpy(stack).cuda()
+    s = torch.zeros((2, 256, 256), dtype=torch.float64, device="cuda")
+    K.temporal_accumulate(dev, s[0], s[1])
+    sx, sxx, n = Tn.temporal_sums(stack)
+    assert np.array_equal(s[0].cpu().numpy(), sx) and np.array_equal(s[1].cpu().numpy(), sxx)
