@@ -218,6 +218,16 @@ struct Fft3 {
     }
     // stage 3: outputs q1 -> register a + B3*q1  <->  k = u + T*(a + B3*q1)
     static __device__ __forceinline__ void stage3(float2 (&v)[E]) { butterflies<R3, E / R3, E / R3>(v); }
+    // one stage-3 butterfly: registers a + (E/R3)*q1, q1 = 0..R3-1 (lets a caller interleave its epilogue)
+    static __device__ __forceinline__ void stage3_one(float2 (&v)[E], int a) {
+        constexpr int B3 = E / R3;
+        float2 t[R3];
+#pragma unroll
+        for (int n = 0; n < R3; ++n) t[n] = v[a + B3 * n];
+        Dft<R3>::run(t);
+#pragma unroll
+        for (int n = 0; n < R3; ++n) v[a + B3 * n] = t[n];
+    }
 
     // The caller guarantees nobody still reads `lds` on entry; on exit other lanes may still be
     // reading it (sync before reuse).  With NV == 2 the sets are processed strictly one after
@@ -246,6 +256,33 @@ struct Fft3 {
         }
         stage3(va);
         if (NV == 2) stage3(vb);
+    }
+
+    // NS register sets that share lane geometry go through the exchange buffer one after the other.
+    // Same entry/exit contract as run().  SERIAL pins the per-set order with sched_barriers (only
+    // useful when the kernel sits at its VGPR cap); otherwise the compiler may overlap set s+1's
+    // butterflies with set s's LDS round trip.
+    template <int NS, bool SERIAL, bool WITH_STAGE3 = true>
+    static __device__ __forceinline__ void run_sets(float2 (&v)[NS][E], int u, int ci, float2* __restrict__ lds,
+                                                    const float2* __restrict__ tw) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            stage1(v[s], u, tw);
+            if (s > 0) __syncthreads();
+            xchg1(v[s], u, ci, lds);
+            if (SERIAL) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            stage2(v[s], u, tw);
+            __syncthreads();
+            xchg2(v[s], u, ci, lds);
+            if (SERIAL) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (WITH_STAGE3) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) stage3(v[s]);
+        }
     }
 };
 

@@ -4,21 +4,21 @@
 //
 // Data flow for a batch of real (ny, nx) frames ("rows first"):
 //
-//   K1 row_r2c   two real rows are packed as one complex row (z = a + i b), one FFT of
-//                length nx, Hermitian split -> half spectra of both rows.  The half
-//                spectrum keeps kx = 0..nx/2-1; the (real) Nyquist bin rides in the imaginary
-//                part of the (real) DC bin, so a row is exactly nx/2 complex values.
-//                Written in a column-tile-major layout: tile ct holds CT adjacent kx for
-//                all ny rows contiguously ([ct][y][c]), so that K2 streams whole tiles.
-//   K2 col       one workgroup owns a tile (CT = 16 columns x ny rows, 256 KiB at 2048^2)
-//                entirely in registers: forward FFT along y, |F|^2 (PSD written shifted,
-//                with its Hermitian mirror), inverse FFT along y of the power spectrum,
-//                written back in place.  Fusing forward and inverse column passes removes
-//                one full read+write of the spectrum (SURVEY.md §8d counts 4 passes).
-//   K3 row_c2r   rebuilds the two-row packing from the half spectra, one inverse FFT of
-//                length nx, shift + normalise -> two autocorrelation rows.
+//   K1 row_r2c   two real rows are packed as one complex row (z = a + i b), one FFT of length nx,
+//                Hermitian split -> half spectra of both rows, kx = 0..nx/2-1, written in a
+//                column-tile-major layout: tile ct holds CT adjacent kx for all ny rows contiguously
+//                ([ct][y][c]), so that K2 streams whole tiles.  The (real) Nyquist bin kx = nx/2 of every
+//                row goes to a small side array (batch, ny) handled by k_nyq.
+//   K2 col       one workgroup owns a tile (CT = 16 columns x ny rows, 256 KiB at 2048^2) entirely in
+//                registers: forward FFT along y, |F|^2 (PSD written shifted, with its Hermitian mirror),
+//                inverse FFT along y of the power spectrum, written back in place.  Fusing forward and
+//                inverse column passes removes one full read+write of the spectrum (SURVEY.md §8d counts
+//                4 passes); two REAL power columns share one complex inverse transform.
+//   k_nyq        the same for the single Nyquist column of each frame (1/1024 of the work).
+//   K3 row_c2r   rebuilds the two-row packing from the half spectra, one inverse FFT of length nx,
+//                shift + normalise -> two autocorrelation rows.
 //
-// All three are HBM-bandwidth bound; see DESIGN.md for the byte accounting.
+// All of them are HBM-bandwidth bound; see DESIGN.md for the byte accounting.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -42,14 +42,27 @@ constexpr int radix2(int n) { return n / 16 < 16 ? n / 16 : 16; }
 constexpr int radix3(int n) { return n / (16 * radix2(n)); }
 template <int N>
 using RowGeom = FftGeom<N, E16, 16, radix2(N), radix3(N), 1>;
-template <int N, int CP>
-using ColGeom = FftGeom<N, E16, 16, radix2(N), radix3(N), CP>;
-// row transforms (two image rows each) per workgroup: 256 lanes, fewer where LDS (64 KiB static) binds
-constexpr int row_seq(int nx) { return nx == 4096 ? 1 : (nx == 64 ? 32 : 256 / (nx / 16)); }
+template <int N, int CI>
+using ColGeom = FftGeom<N, E16, 16, radix2(N), radix3(N), CI>;
+// single transforms (two image rows, or one Nyquist column) per workgroup: 256 lanes, fewer where the
+// 64 KiB static LDS limit binds
+constexpr int row_seq(int n) { return n == 4096 ? 1 : (n == 64 ? 32 : 256 / (n / 16)); }
 
 // spectrum element index in the tile-major layout
 __device__ __forceinline__ size_t spec_index(size_t frame, int nt, int ny, int ct_w, int y, int kx) {
     return ((frame * nt + (kx / ct_w)) * (size_t)ny + y) * ct_w + (kx % ct_w);
+}
+
+// c = a * conj(b), optionally whitened: c / (|c| + eps)   (signal/tracking.py:280-281)
+template <bool WHITEN>
+__device__ __forceinline__ float2 cross_power(float2 a, float2 b, float eps) {
+    float2 c = make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+    if (WHITEN) {
+        const float m = sqrtf(fmaf(c.x, c.x, c.y * c.y)) + eps;
+        c.x /= m;
+        c.y /= m;
+    }
+    return c;
 }
 
 // ------------------------------------------------------------------------------------ K1
@@ -62,11 +75,11 @@ struct RowSrc {
     int pad;
 };
 
-// grid (ny/2/SEQ, batch); block T*SEQ.  ct_w = tile width (complex columns) of the spectrum layout.
+// grid (ceil(ny/2/SEQ), batch); block T*SEQ.  ct_w = tile width (complex columns) of the spectrum layout.
 template <int NX, int SEQ, bool SRC>
 __global__ void __launch_bounds__((NX / E16) * SEQ)
-k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, const float2* __restrict__ tw, int ny, int ct_w,
-          const RowSrc* __restrict__ srcs) {
+k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, float* __restrict__ nyq_rows,
+          const float2* __restrict__ tw, int ny, int ct_w, const RowSrc* __restrict__ srcs) {
     using G = RowGeom<NX>;
     constexpr int T = G::T, E = E16;
     __shared__ float2 lds_all[SEQ * G::LDS_ELEMS];
@@ -111,10 +124,12 @@ k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, const float2*
         const float2 z = v[j], zr = lds[(NX - k) & (NX - 1)];
         float2 a = make_float2(0.5f * (z.x + zr.x), 0.5f * (z.y - zr.y));
         float2 b = make_float2(0.5f * (z.y + zr.y), 0.5f * (zr.x - z.x));
-        if (k == 0) {  // DC and Nyquist are both real: pack them
+        if (k == 0) {  // DC bins are real; the (real) Nyquist bins of both rows go to the side array
             const float2 zn = lds[NX / 2];
-            a = make_float2(z.x, zn.x);
-            b = make_float2(z.y, zn.y);
+            a = make_float2(z.x, 0.f);
+            b = make_float2(z.y, 0.f);
+            nyq_rows[frame * ny + 2 * pair] = zn.x;
+            nyq_rows[frame * ny + 2 * pair + 1] = zn.y;
         }
         const size_t o = spec_index(frame, nt, ny, ct_w, 2 * pair, k);
         spec[o] = a;
@@ -131,151 +146,267 @@ struct ColArgs {
     float2* full;     // (batch, ny, nx) complex, COL_SPECTRUM only
     const float2* tw;
     float psd_scale;
-    int nx, nt;       // nt = number of column tiles = (nx/2)/CT
+    int nx;
     unsigned flags;
 };
 
-// block CP*NY/16; CT = 2*CP columns per tile.  Tile 0 holds the packed DC/Nyquist column and is
-// handled by its own instantiation (TILE0, grid (1, batch)); the others run with grid (nt-1, batch).
-template <int NY, int CP, int MODE, bool TILE0>
-__global__ void __launch_bounds__(CP * (NY / E16)) k_col(ColArgs p) {
-    using G = ColGeom<NY, CP>;
-    constexpr int T = G::T, E = E16, CT = 2 * CP;
+// Column-tile geometry: a lane holds NC adjacent columns (NC*8 bytes per row), CPT lanes span the tile
+// (CT = NC*CPT columns = whole 128-B lines per row), T = NY/16 lanes run along y.
+//   NY <= 2048: NC = 4, CPT = 4 -> CT = 16; 512 lanes at 2048 (8 waves, up to 256 VGPRs: the 256-KiB tile
+//               sits in registers with room for the butterflies)
+//   NY == 4096: NC = 2, CPT = 4 -> CT = 8; 1024 lanes (a 16-column tile would need the whole register file)
+template <int NY>
+struct ColCfg {
+    static constexpr int NC = NY == 4096 ? 2 : 4;
+    static constexpr int CPT = 4;
+    static constexpr int CT = NC * CPT;
+    static constexpr int THREADS = CPT * (NY / E16);
+    using G = ColGeom<NY, CPT>;
+    static constexpr size_t LDS_BYTES = sizeof(float2) * (size_t)G::LDS_ELEMS * CPT;
+    static constexpr bool SERIAL = THREADS > 512;  // at the 128-VGPR cap: pin the per-set order
+};
+
+// 4-byte-aligned 16-byte store (gfx950 runs in unaligned access mode: one global_store_dwordx4)
+struct __attribute__((packed, aligned(4))) float4_u {
+    float x, y, z, w;
+};
+
+template <int NC>
+__device__ __forceinline__ void store_cols(float2* __restrict__ rowp, const float2 (&c)[NC]) {
+#pragma unroll
+    for (int h = 0; h < NC / 2; ++h)
+        *reinterpret_cast<float4*>(rowp + 2 * h) = make_float4(c[2 * h].x, c[2 * h].y, c[2 * h + 1].x, c[2 * h + 1].y);
+}
+
+// grid (nt, batch), block ColCfg<NY>::THREADS.
+template <int NY, int MODE>
+__global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
+    using Cfg = ColCfg<NY>;
+    using G = typename Cfg::G;
+    constexpr int T = G::T, E = E16, NC = Cfg::NC, CPT = Cfg::CPT, CT = Cfg::CT;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int cp = threadIdx.x % CP, u = threadIdx.x / CP;
-    const int ct = TILE0 ? 0 : blockIdx.x + 1, nt = p.nt;
+    const int cp = threadIdx.x % CPT, u = threadIdx.x / CPT;
+    const int nt = gridDim.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 when nt % 8 == 0).  Give each XCD a
+    // contiguous range of column tiles: the two 64-B halves of every 128-B PSD line are then written by
+    // neighbours on ONE XCD and merge in its L2 (speed only; any placement is correct).
+    const int ct = (nt % 8 == 0) ? (blockIdx.x % 8) * (nt / 8) + blockIdx.x / 8 : blockIdx.x;
     const size_t frame = blockIdx.y;
     const int nx = p.nx;
     float2* tile = p.spec + ((frame * nt + ct) * (size_t)NY) * CT;
-    const unsigned toff = (unsigned)u * CT + 2 * cp;  // element offset of (row u, column pair cp) in the tile
-    float2 va[E], vb[E];
+    const unsigned toff = (unsigned)u * CT + NC * cp;  // element offset of (row u, first column of this lane)
+    float2 v[NC][E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const float4 q = *reinterpret_cast<const float4*>(tile + (size_t)(T * j * CT) + toff);
-        va[j] = make_float2(q.x, q.y);
-        vb[j] = make_float2(q.z, q.w);
-    }
-    Fft3<G, 2>::run(va, vb, u, cp, lds, p.tw);
-    // va[j] = F[ky = u + T j][kx0], vb[j] = F[ky][kx0 + 1]
-    const int kx0 = ct * CT + 2 * cp;
-    const bool packed = TILE0 && cp == 0;  // column 0 carries the DC (re) and Nyquist (im) rows' transforms
-    if (TILE0) {                           // publish column 0 in natural order for the Hermitian split
-        __syncthreads();
-        if (cp == 0) {
 #pragma unroll
-            for (int j = 0; j < E; ++j) lds[u + T * j] = va[j];
+        for (int h = 0; h < NC / 2; ++h) {
+            const float4 q = *reinterpret_cast<const float4*>(tile + (size_t)(T * j * CT) + toff + 2 * h);
+            v[2 * h][j] = make_float2(q.x, q.y);
+            v[2 * h + 1][j] = make_float2(q.z, q.w);
         }
-        __syncthreads();
     }
-    // F[ky][0] and F[ky][nx/2] from Z[ky], Z[-ky] of the packed column
-    auto split = [&](int j, float2& f0, float2& fn) {
-        const int ky = u + T * j;
-        const float2 z = va[j], zr = lds[(NY - ky) & (NY - 1)];
-        f0 = make_float2(0.5f * (z.x + zr.x), 0.5f * (z.y - zr.y));
-        fn = make_float2(0.5f * (z.y + zr.y), 0.5f * (zr.x - z.x));
-    };
+    Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL, MODE != COL_PSD_AC>(v, u, cp, lds, p.tw);
+    // v[c][j] = F[ky = u + T j][kx0 + c]   (COL_PSD_AC: after the stage-3 butterflies done below)
+    const int kx0 = ct * CT + NC * cp;
 
-    if (MODE == COL_FORWARD) {
-        // keep the 2-D half spectrum in the tile; the Nyquist column goes to the side buffer p.full (batch, NY)
+    if (MODE == COL_FORWARD) {  // keep the 2-D half spectrum in the tile
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            float2 f0 = va[j], fn;
-            if (packed) {
-                split(j, f0, fn);
-                p.full[frame * NY + u + T * j] = fn;
-            }
-            *reinterpret_cast<float4*>(tile + (size_t)(T * j * CT) + toff) = make_float4(f0.x, f0.y, vb[j].x, vb[j].y);
+            float2 c[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) c[k] = v[k][j];
+            store_cols<NC>(tile + (size_t)(T * j * CT) + toff, c);
         }
         return;
     }
 
-    if (MODE == COL_SPECTRUM) {
+    if (MODE == COL_SPECTRUM) {  // full shifted complex spectrum: direct half + conjugate mirror
         float2* out = p.full + frame * (size_t)NY * nx;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const int ky = u + T * j;
             const unsigned rd = (unsigned)((ky + NY / 2) & (NY - 1)) * nx, rm = (unsigned)((NY / 2 - ky) & (NY - 1)) * nx;
-            float2 f0 = va[j], fn;
-            if (packed) {
-                split(j, f0, fn);
-                out[rd] = fn;
-            }
-            *reinterpret_cast<float4*>(&out[rd + nx / 2 + kx0]) = make_float4(f0.x, f0.y, vb[j].x, vb[j].y);
-            if (kx0 >= 1) out[rm + nx / 2 - kx0] = make_float2(f0.x, -f0.y);
-            out[rm + nx / 2 - kx0 - 1] = make_float2(vb[j].x, -vb[j].y);
+            float2 c[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) c[k] = v[k][j];
+            store_cols<NC>(out + rd + nx / 2 + kx0, c);
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                if (kx0 + k >= 1) out[rm + nx / 2 - kx0 - k] = make_float2(c[k].x, -c[k].y);
         }
         return;
     }
 
-    // ---- COL_PSD_AC: power spectrum, optional PSD store, inverse transform along y
+    // ---- COL_PSD_AC: power spectrum, optional PSD store (direct + Hermitian mirror), inverse transform.
+    // Two REAL power columns ride one complex transform (Pa + i Pb), separated afterwards with the
+    // Hermitian symmetry in y: half the butterflies and LDS traffic of a column-by-column inverse.
+    // The last forward butterflies are interleaved with the |F|^2 epilogue (register pressure), and the
+    // row index is laundered so that the 32 store offsets are not precomputed at kernel entry.
     const float s = p.psd_scale;
     float* psd = p.psd ? p.psd + frame * (size_t)NY * nx : nullptr;
+    int uu = u;
+    asm volatile("" : "+v"(uu));
+    float2 w[NC / 2][E];
+    constexpr int B3 = E / G::R3;
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const int ky = u + T * j;
-        float2 f0 = va[j], fn = make_float2(0.f, 0.f);
-        if (packed) split(j, f0, fn);
-        const float pa = f0.x * f0.x + f0.y * f0.y;
-        const float pb = vb[j].x * vb[j].x + vb[j].y * vb[j].y;
-        const float pn = fn.x * fn.x + fn.y * fn.y;
-        if (psd) {
-            const unsigned rd = (unsigned)((ky + NY / 2) & (NY - 1)) * nx, rm = (unsigned)((NY / 2 - ky) & (NY - 1)) * nx;
-            *reinterpret_cast<float2*>(&psd[rd + nx / 2 + kx0]) = make_float2(pa * s, pb * s);
-            if (kx0 >= 1) psd[rm + nx / 2 - kx0] = pa * s;
-            psd[rm + nx / 2 - kx0 - 1] = pb * s;
-            if (packed) psd[rd] = pn * s;
+    for (int a = 0; a < B3; ++a) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) Fft3<G, 1>::stage3_one(v[k], a);
+#pragma unroll
+        for (int q = 0; q < G::R3; ++q) {
+            const int j = a + B3 * q;
+            const int ky = uu + T * j;
+            float pw[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) pw[k] = v[k][j].x * v[k][j].x + v[k][j].y * v[k][j].y;
+            if (psd) {
+                const unsigned rd = (unsigned)((ky + NY / 2) & (NY - 1)) * nx, rm = (unsigned)((NY / 2 - ky) & (NY - 1)) * nx;
+                if (NC == 4)
+                    *reinterpret_cast<float4*>(&psd[rd + nx / 2 + kx0]) =
+                        make_float4(pw[0] * s, pw[1] * s, pw[2 % NC] * s, pw[3 % NC] * s);
+                else
+                    *reinterpret_cast<float2*>(&psd[rd + nx / 2 + kx0]) = make_float2(pw[0] * s, pw[1] * s);
+                // Hermitian mirror: columns nx/2 - kx0 - k, descending -> one reversed (4-byte aligned) vector store
+                if (NC == 4 && kx0 >= 1) {
+                    float4_u m;
+                    m.x = pw[3 % NC] * s;
+                    m.y = pw[2 % NC] * s;
+                    m.z = pw[1] * s;
+                    m.w = pw[0] * s;
+                    *reinterpret_cast<float4_u*>(&psd[rm + nx / 2 - kx0 - 3]) = m;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NC; ++k)
+                        if (kx0 + k >= 1) psd[rm + nx / 2 - kx0 - k] = pw[k] * s;
+                }
+            }
+            // inverse inputs, already (im, re)-swapped so that the forward code inverts: Pa + i Pb -> (Pb, Pa)
+#pragma unroll
+            for (int h = 0; h < NC / 2; ++h) w[h][j] = make_float2(pw[2 * h + 1], pw[2 * h]);
         }
-        // inverse input, already (im, re)-swapped.
-        //  tile 0: column a -> (Pnyq, Pdc) on the packed lanes else (0, Pa); column b -> (0, Pb)
-        //  others: the two REAL power columns ride one complex transform: Pa + i Pb -> (Pb, Pa)
-        if (TILE0) {
-            va[j] = make_float2(pn, pa);
-            vb[j] = make_float2(0.f, pb);
-        } else {
-            va[j] = make_float2(pb, pa);
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
-    // Launder the twiddle pointer: otherwise the compiler keeps the first transform's 30 twiddles
-    // alive across the whole kernel (they are provably the same loads) and spills.
+    if (kx0 == 0 && u == 0 && (p.flags & B4D_REMOVE_MEAN)) w[0][0].y = 0.f;  // DC bin: ky = 0 <-> u = 0, j = 0
+    // Launder pointer/offset: otherwise the compiler keeps the first transform's twiddles and the 64-bit
+    // load addresses alive across the whole kernel (provably identical loads / addresses).
     const float2* tw2 = p.tw;
     asm volatile("" : "+s"(tw2));
-    unsigned toff2 = toff;  // same for the store addresses (16 x 64-bit pairs would stay live from the loads)
+    unsigned toff2 = toff;
     asm volatile("" : "+v"(toff2));
     __syncthreads();
-    if (TILE0) {
-        if (packed && u == 0 && (p.flags & B4D_REMOVE_MEAN)) va[0].y = 0.f;  // DC bin: ky = 0 <-> u = 0, j = 0
-        Fft3<G, 2>::run(va, vb, u, cp, lds, tw2);
+    Fft3<G, 1>::template run_sets<NC / 2, Cfg::SERIAL>(w, u, cp, lds, tw2);
+    // V[y] = Ga[y] + i Gb[y] with Ga, Gb Hermitian in y: split with V[-y], one set at a time
+    float2 vr[NC / 2][E];
 #pragma unroll
-        for (int j = 0; j < E; ++j)
-            *reinterpret_cast<float4*>(tile + (size_t)(T * j * CT) + toff2) =
-                make_float4(va[j].y, va[j].x, vb[j].y, vb[j].x);
-    } else {
-        Fft3<G, 1>::run(va, va, u, cp, lds, tw2);
-        // V[y] = Ga[y] + i Gb[y] with Ga, Gb Hermitian in y: split with V[-y]
+    for (int h = 0; h < NC / 2; ++h) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < E; ++j) lds[(u + T * j) * CP + cp] = make_float2(va[j].y, va[j].x);
+        for (int j = 0; j < E; ++j) lds[(u + T * j) * CPT + cp] = make_float2(w[h][j].y, w[h][j].x);
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < E; ++j) vr[h][j] = lds[((NY - (u + T * j)) & (NY - 1)) * CPT + cp];
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        float2 c[NC];
+#pragma unroll
+        for (int h = 0; h < NC / 2; ++h) {
+            const float2 z = make_float2(w[h][j].y, w[h][j].x), zr = vr[h][j];
+            c[2 * h] = make_float2(0.5f * (z.x + zr.x), 0.5f * (z.y - zr.y));
+            c[2 * h + 1] = make_float2(0.5f * (z.y + zr.y), 0.5f * (zr.x - z.x));
+        }
+        store_cols<NC>(tile + (size_t)(T * j * CT) + toff2, c);
+    }
+}
+
+// ------------------------------------------------------------------------------------ Nyquist column
+enum NyqMode { NYQ_PSD_AC = 0, NYQ_SPECTRUM = 1, NYQ_FORWARD = 2, NYQ_PROD = 3, NYQ_PROD_WHITEN = 4 };
+
+struct NyqArgs {
+    const float* rows;   // (items, NY) real Nyquist bins from K1                      [PSD_AC, SPECTRUM, FORWARD]
+    float2* f_out;       // (items, NY) complex column spectra                          [FORWARD]
+    float* g_out;        // (items, NY) real inverse-column output, consumed by K3      [PSD_AC, PROD]
+    float* psd;          // (items, NY, nx) or null: column 0 of the shifted PSD        [PSD_AC]
+    float2* full;        // (items, NY, nx): column 0 of the shifted complex spectrum   [SPECTRUM]
+    const float2* fa;    // column spectra of the two operands + per-pair indices       [PROD]
+    const float2* fb;
+    const int* idx_a;
+    const int* idx_b;
+    const float2* tw;
+    float psd_scale, eps;
+    int nx, items;
+};
+
+// grid (ceil(items/SEQ)), block T*SEQ: one length-NY transform per T lanes.
+template <int NY, int SEQ, int MODE>
+__global__ void __launch_bounds__((NY / E16) * SEQ) k_nyq(NyqArgs p) {
+    using G = RowGeom<NY>;
+    constexpr int T = G::T, E = E16;
+    __shared__ float2 lds_all[SEQ * G::LDS_ELEMS];
+    const int seq = threadIdx.x / T, u = threadIdx.x % T;
+    const int item = blockIdx.x * SEQ + seq;
+    const bool live = item < p.items;
+    const size_t it = live ? item : 0;
+    float2* lds = lds_all + seq * G::LDS_ELEMS;
+    float2 v[E];
+    if (MODE == NYQ_PROD || MODE == NYQ_PROD_WHITEN) {
+        const size_t ia = p.idx_a ? p.idx_a[it] : it, ib = p.idx_b ? p.idx_b[it] : it;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const float2 z = make_float2(va[j].y, va[j].x), zr = lds[((NY - (u + T * j)) & (NY - 1)) * CP + cp];
-            *reinterpret_cast<float4*>(tile + (size_t)(T * j * CT) + toff2) =
-                make_float4(0.5f * (z.x + zr.x), 0.5f * (z.y - zr.y), 0.5f * (z.y + zr.y), 0.5f * (zr.x - z.x));
+            const int ky = u + T * j;
+            const float2 c = cross_power<MODE == NYQ_PROD_WHITEN>(p.fa[ia * NY + ky], p.fb[ib * NY + ky], p.eps);
+            v[j] = make_float2(c.y, c.x);  // swapped: inverse transform
         }
+        Fft3<G, 1>::run(v, v, u, 0, lds, p.tw);
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) p.g_out[it * NY + u + T * j] = v[j].y;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) v[j] = make_float2(p.rows[it * NY + u + T * j], 0.f);
+    Fft3<G, 1>::run(v, v, u, 0, lds, p.tw);
+    if (MODE == NYQ_FORWARD) {
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) p.f_out[it * NY + u + T * j] = v[j];
+        }
+        return;
+    }
+    if (MODE == NYQ_SPECTRUM) {
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                p.full[(it * NY + ((u + T * j + NY / 2) & (NY - 1))) * (size_t)p.nx] = v[j];
+        }
+        return;
+    }
+    // NYQ_PSD_AC
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const float pw = v[j].x * v[j].x + v[j].y * v[j].y;
+        if (live && p.psd) p.psd[(it * NY + ((u + T * j + NY / 2) & (NY - 1))) * (size_t)p.nx] = pw * p.psd_scale;
+        v[j] = make_float2(0.f, pw);
+    }
+    __syncthreads();
+    Fft3<G, 1>::run(v, v, u, 0, lds, p.tw);
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) p.g_out[it * NY + u + T * j] = v[j].y;
     }
 }
 
 // ------------------------------------------------------------------------------------ K3
 struct RowOutArgs {
-    const float2* g;   // tile-major inverse-column output
-    float* out;        // (batch, ny, nx) float32 shifted
-    float* peak;       // (batch) zero-lag values
+    const float2* g;     // tile-major inverse-column output
+    const float* gnyq;   // (batch, ny) inverse-column output of the Nyquist column (real)
+    float* out;          // (batch, ny, nx) float32 shifted
+    float* peak;         // (batch) zero-lag values
     const float2* tw;
-    float scale;       // used when !NORM_PEAK
+    float scale;         // used when !NORM_PEAK
     int ny, ct_w;
     unsigned flags;
-    float* part_val;   // C2R_MAG: per-workgroup arg-max partials (batch, gridDim.x)
+    float* part_val;     // C2R_MAG: per-workgroup arg-max partials (batch, gridDim.x)
     int* part_idx;
 };
 
@@ -289,7 +420,7 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
     }
 }
 
-// grid (ny/2/SEQ, batch) -- or (1, batch) for C2R_PEAK; block T*SEQ.
+// grid (ceil(ny/2/SEQ), batch) -- or (1, batch) for C2R_PEAK; block T*SEQ.
 //   C2R_OUT   shifted real output, scaled (flags & NORM_PEAK: by 1/peak[frame], zero lag forced to 1)
 //   C2R_PEAK  only the zero-lag value of each frame -> peak[frame]
 //   C2R_MAG   |value| * scale (signal/tracking.py:283-285) + per-workgroup arg-max partials
@@ -303,16 +434,17 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
     const size_t frame = blockIdx.y;
     const int ny = p.ny, ct_w = p.ct_w, nt = (NX / 2) / ct_w;
     const bool live = 2 * pair < ny;
+    const int yl = live ? 2 * pair : 0;
     float2* lds = lds_all + seq * G::LDS_ELEMS;
     float2 v[E];
 #pragma unroll
     for (int j = 0; j < E / 2; ++j) {
         const int k = u + T * j;
-        const size_t o = spec_index(frame, nt, ny, ct_w, live ? 2 * pair : 0, k);
+        const size_t o = spec_index(frame, nt, ny, ct_w, yl, k);
         const float2 a = p.g[o], b = p.g[o + ct_w];
-        if (k == 0) {  // packed: a = (A_dc, A_nyq), b = (B_dc, B_nyq), all real
-            v[j] = make_float2(b.x, a.x);            // swap(A_dc + i B_dc)
-            lds[NX / 2] = make_float2(b.y, a.y);     // swap(A_nyq + i B_nyq)
+        if (k == 0) {  // DC and Nyquist bins of both rows are real
+            v[j] = make_float2(b.x, a.x);                                                       // swap(A_dc + i B_dc)
+            lds[NX / 2] = make_float2(p.gnyq[frame * ny + yl + 1], p.gnyq[frame * ny + yl]);  // swap(A_nyq + i B_nyq)
         } else {
             v[j] = make_float2(a.y + b.x, a.x - b.y);        // swap(A + iB)
             lds[NX - k] = make_float2(b.x - a.y, a.x + b.y);  // swap(conj A + i conj B)
@@ -392,13 +524,15 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
 using namespace b4d;
 
 struct b4d_plan {
-    int ny, nx, chunk, ct_w, cp;
-    float2* tw_x = nullptr;   // nx-point twiddles
-    float2* tw_y = nullptr;   // ny-point twiddles
-    float2* spec = nullptr;   // chunk * ny * nx/2
-    float* peak = nullptr;    // chunk
+    int ny, nx, chunk, ct_w;
+    float2* tw_x = nullptr;    // nx-point twiddles
+    float2* tw_y = nullptr;    // ny-point twiddles
+    float2* spec = nullptr;    // chunk * ny * nx/2
+    float* nyq_rows = nullptr; // chunk * ny: Nyquist bins after the row pass
+    float* gnyq = nullptr;     // chunk * ny: Nyquist column after the inverse column pass
+    float* peak = nullptr;     // chunk
     size_t ws_bytes = 0;
-    void* track_ws = nullptr; // lazily grown arena of the xcorr / tracking entry points
+    void* track_ws = nullptr;  // lazily grown arena of the xcorr / tracking entry points
     size_t track_bytes = 0;
 };
 
@@ -415,78 +549,99 @@ static inline int make_twiddles(int n, float2** out) {
     return B4D_OK;
 }
 
-template <int NY, int CP, int MODE, bool TILE0>
-static int launch_col1(const ColArgs& a, int gx, int batch, hipStream_t st) {
-    using G = ColGeom<NY, CP>;
-    const size_t lds = sizeof(float2) * (size_t)G::LDS_ELEMS * CP;
+#define B4D_SIZE_SWITCH(n, CALL)        \
+    switch (n) {                        \
+        case 64: return CALL(64);       \
+        case 128: return CALL(128);     \
+        case 256: return CALL(256);     \
+        case 512: return CALL(512);     \
+        case 1024: return CALL(1024);   \
+        case 2048: return CALL(2048);   \
+        case 4096: return CALL(4096);   \
+    }
+
+template <int NY, int MODE>
+static int launch_col(const ColArgs& a, int ntiles, int batch, hipStream_t st) {
+    using Cfg = ColCfg<NY>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col<NY, CP, MODE, TILE0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col<NY, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     });
     B4D_HIP(attr_err);
-    if (gx < 1) return B4D_OK;
-    hipLaunchKernelGGL((k_col<NY, CP, MODE, TILE0>), dim3(gx, batch), dim3(CP * (NY / E16)), lds, st, a);
+    hipLaunchKernelGGL((k_col<NY, MODE>), dim3(ntiles, batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
-template <int NY, int CP, int MODE>
-static int launch_col(const ColArgs& a, int ntiles, int batch, hipStream_t st) {
-    int rc = launch_col1<NY, CP, MODE, false>(a, ntiles - 1, batch, st);
-    if (rc) return rc;
-    return launch_col1<NY, CP, MODE, true>(a, 1, batch, st);
+template <int MODE>
+static int dispatch_col(const b4d_plan* pl, const ColArgs& a, int batch, hipStream_t st) {
+    const int ntiles = (pl->nx / 2) / pl->ct_w;
+#define B4D_CALL(N) launch_col<N, MODE>(a, ntiles, batch, st)
+    B4D_SIZE_SWITCH(pl->ny, B4D_CALL)
+#undef B4D_CALL
+    return fail(B4D_ESIZE, "unsupported ny");
 }
 
+template <int NY, int MODE>
+static int launch_nyq(const NyqArgs& a, hipStream_t st) {
+    constexpr int SEQ = row_seq(NY);
+    hipLaunchKernelGGL((k_nyq<NY, SEQ, MODE>), dim3((a.items + SEQ - 1) / SEQ), dim3((NY / E16) * SEQ), 0, st, a);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
 template <int MODE>
-static int dispatch_col(const b4d_plan* pl, const ColArgs& a_in, int batch, hipStream_t st) {
-    const int ntiles = (pl->nx / 2) / pl->ct_w;
-    ColArgs a = a_in;
-    a.nt = ntiles;
-    switch (pl->ny) {
-        case 64: return launch_col<64, 8, MODE>(a, ntiles, batch, st);
-        case 128: return launch_col<128, 8, MODE>(a, ntiles, batch, st);
-        case 256: return launch_col<256, 8, MODE>(a, ntiles, batch, st);
-        case 512: return launch_col<512, 8, MODE>(a, ntiles, batch, st);
-        case 1024: return launch_col<1024, 8, MODE>(a, ntiles, batch, st);
-        case 2048: return launch_col<2048, 8, MODE>(a, ntiles, batch, st);
-        case 4096: return launch_col<4096, 4, MODE>(a, ntiles, batch, st);
-    }
+static int dispatch_nyq(const b4d_plan* pl, NyqArgs a, int items, hipStream_t st) {
+    a.items = items;
+    a.tw = pl->tw_y;
+    a.nx = pl->nx;
+#define B4D_CALL(N) launch_nyq<N, MODE>(a, st)
+    B4D_SIZE_SWITCH(pl->ny, B4D_CALL)
+#undef B4D_CALL
     return fail(B4D_ESIZE, "unsupported ny");
 }
 
 template <int NX>
-static int launch_r2c(const b4d_plan* pl, const float* in, float2* spec, const RowSrc* srcs, int batch, hipStream_t st) {
+static int launch_r2c(const b4d_plan* pl, const float* in, float2* spec, float* nyq_rows, const RowSrc* srcs, int batch,
+                      hipStream_t st) {
     constexpr int SEQ = row_seq(NX);
     const dim3 grid((pl->ny / 2 + SEQ - 1) / SEQ, batch), block((NX / E16) * SEQ);
     if (srcs)
-        hipLaunchKernelGGL((k_row_r2c<NX, SEQ, true>), grid, block, 0, st, in, spec, pl->tw_x, pl->ny, pl->ct_w, srcs);
+        hipLaunchKernelGGL((k_row_r2c<NX, SEQ, true>), grid, block, 0, st, in, spec, nyq_rows, pl->tw_x, pl->ny,
+                           pl->ct_w, srcs);
     else
-        hipLaunchKernelGGL((k_row_r2c<NX, SEQ, false>), grid, block, 0, st, in, spec, pl->tw_x, pl->ny, pl->ct_w, srcs);
+        hipLaunchKernelGGL((k_row_r2c<NX, SEQ, false>), grid, block, 0, st, in, spec, nyq_rows, pl->tw_x, pl->ny,
+                           pl->ct_w, srcs);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
-// rows -> half spectra into `spec` (default: the plan's chunk workspace); srcs != null selects ROI / z-score sources
+// rows -> half spectra into `spec` / `nyq_rows` (default: the plan's chunk workspace); srcs != null selects
+// ROI / z-score sources
 static int dispatch_r2c(const b4d_plan* pl, const float* in, int batch, hipStream_t st, float2* spec = nullptr,
-                        const RowSrc* srcs = nullptr) {
+                        float* nyq_rows = nullptr, const RowSrc* srcs = nullptr) {
     if (!spec) spec = pl->spec;
-    switch (pl->nx) {
-        case 64: return launch_r2c<64>(pl, in, spec, srcs, batch, st);
-        case 128: return launch_r2c<128>(pl, in, spec, srcs, batch, st);
-        case 256: return launch_r2c<256>(pl, in, spec, srcs, batch, st);
-        case 512: return launch_r2c<512>(pl, in, spec, srcs, batch, st);
-        case 1024: return launch_r2c<1024>(pl, in, spec, srcs, batch, st);
-        case 2048: return launch_r2c<2048>(pl, in, spec, srcs, batch, st);
-        case 4096: return launch_r2c<4096>(pl, in, spec, srcs, batch, st);
-    }
+    if (!nyq_rows) nyq_rows = pl->nyq_rows;
+#define B4D_CALL(N) launch_r2c<N>(pl, in, spec, nyq_rows, srcs, batch, st)
+    B4D_SIZE_SWITCH(pl->nx, B4D_CALL)
+#undef B4D_CALL
     return fail(B4D_ESIZE, "unsupported nx");
 }
 
+// mode: C2R_OUT (with a C2R_PEAK pre-pass when NORM_PEAK) or C2R_MAG.  ev: optional event sink (timed runs).
 template <int NX>
-static int launch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, hipStream_t st, std::vector<hipEvent_t>* ev) {
+static int launch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, int mode, hipStream_t st,
+                      std::vector<hipEvent_t>* ev, int* nblk) {
     constexpr int SEQ = row_seq(NX);
+    const dim3 grid((pl->ny / 2 + SEQ - 1) / SEQ, batch), block((NX / E16) * SEQ);
+    if (nblk) *nblk = grid.x;
+    if (batch < 1) return B4D_OK;
+    if (mode == C2R_MAG) {
+        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_MAG>), grid, block, 0, st, a);
+        B4D_HIP(hipGetLastError());
+        return B4D_OK;
+    }
     if (a.flags & B4D_NORM_PEAK) {
-        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_PEAK>), dim3(1, batch), dim3((NX / E16) * SEQ), 0, st, a);
+        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_PEAK>), dim3(1, batch), block, 0, st, a);
         B4D_HIP(hipGetLastError());
         if (ev) {
             hipEvent_t e;
@@ -495,21 +650,14 @@ static int launch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, hipStr
             B4D_HIP(hipEventRecord(e, st));
         }
     }
-    hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_OUT>), dim3((pl->ny / 2 + SEQ - 1) / SEQ, batch), dim3((NX / E16) * SEQ), 0, st, a);
+    hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_OUT>), grid, block, 0, st, a);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
-static int dispatch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, hipStream_t st,
-                        std::vector<hipEvent_t>* ev = nullptr) {
-    switch (pl->nx) {
-        case 64: return launch_c2r<64>(pl, a, batch, st, ev);
-        case 128: return launch_c2r<128>(pl, a, batch, st, ev);
-        case 256: return launch_c2r<256>(pl, a, batch, st, ev);
-        case 512: return launch_c2r<512>(pl, a, batch, st, ev);
-        case 1024: return launch_c2r<1024>(pl, a, batch, st, ev);
-        case 2048: return launch_c2r<2048>(pl, a, batch, st, ev);
-        case 4096: return launch_c2r<4096>(pl, a, batch, st, ev);
-    }
+static int dispatch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, hipStream_t st, int mode = C2R_OUT,
+                        std::vector<hipEvent_t>* ev = nullptr, int* nblk = nullptr) {
+#define B4D_CALL(N) launch_c2r<N>(pl, a, batch, mode, st, ev, nblk)
+    B4D_SIZE_SWITCH(pl->nx, B4D_CALL)
+#undef B4D_CALL
     return fail(B4D_ESIZE, "unsupported nx");
 }
-

@@ -26,8 +26,7 @@ int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out) {
     p->ny = ny;
     p->nx = nx;
     p->chunk = chunk;
-    p->cp = (ny == 4096) ? 4 : 8;
-    p->ct_w = 2 * p->cp;
+    p->ct_w = (ny == 4096) ? 8 : 16;
     int rc = make_twiddles(nx, &p->tw_x);
     if (rc == B4D_OK) rc = make_twiddles(ny, &p->tw_y);
     if (rc != B4D_OK) {
@@ -36,6 +35,8 @@ int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out) {
     }
     p->ws_bytes = sizeof(float2) * (size_t)chunk * ny * (nx / 2);
     hipError_t e = hipMalloc((void**)&p->spec, p->ws_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->nyq_rows, sizeof(float) * (size_t)chunk * ny);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->gnyq, sizeof(float) * (size_t)chunk * ny);
     if (e == hipSuccess) e = hipMalloc((void**)&p->peak, sizeof(float) * chunk);
     if (e != hipSuccess) {
         b4d_plan_destroy(p);
@@ -51,6 +52,8 @@ int b4d_plan_destroy(b4d_plan* p) {
     if (p->tw_y) (void)hipFree(p->tw_y);
     if (p->spec) (void)hipFree(p->spec);
     if (p->peak) (void)hipFree(p->peak);
+    if (p->nyq_rows) (void)hipFree(p->nyq_rows);
+    if (p->gnyq) (void)hipFree(p->gnyq);
     if (p->track_ws) (void)hipFree(p->track_ws);
     delete p;
     return B4D_OK;
@@ -90,10 +93,17 @@ static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float
         ca.nx = pl->nx;
         ca.flags = flags;
         if ((rc = dispatch_col<COL_PSD_AC>(pl, ca, nb, st))) break;
+        NyqArgs na{};
+        na.rows = pl->nyq_rows;
+        na.g_out = pl->gnyq;
+        na.psd = ca.psd;
+        na.psd_scale = psd_scale;
+        if ((rc = dispatch_nyq<NYQ_PSD_AC>(pl, na, nb, st))) break;
         if ((rc = mark())) break;
         if (autocorr) {
             RowOutArgs ra{};
             ra.g = pl->spec;
+            ra.gnyq = pl->gnyq;
             ra.out = autocorr + b0 * fpix;
             ra.peak = pl->peak;
             ra.tw = pl->tw_x;
@@ -101,7 +111,7 @@ static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float
             ra.ny = pl->ny;
             ra.ct_w = pl->ct_w;
             ra.flags = flags;
-            if ((rc = dispatch_c2r(pl, ra, nb, st, kernel_ms ? &ev : nullptr))) break;
+            if ((rc = dispatch_c2r(pl, ra, nb, st, C2R_OUT, kernel_ms ? &ev : nullptr))) break;
         }
         if ((rc = mark())) break;
     }
@@ -168,6 +178,11 @@ int b4d_fft2d(b4d_plan* pl, const float* frames, int batch, float* out_c64, void
         ca.tw = pl->tw_y;
         ca.nx = pl->nx;
         rc = dispatch_col<COL_SPECTRUM>(pl, ca, nb, st);
+        if (rc) return rc;
+        NyqArgs na{};
+        na.rows = pl->nyq_rows;
+        na.full = ca.full;
+        rc = dispatch_nyq<NYQ_SPECTRUM>(pl, na, nb, st);
         if (rc) return rc;
     }
     return B4D_OK;

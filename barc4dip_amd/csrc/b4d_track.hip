@@ -52,9 +52,7 @@ __global__ void __launch_bounds__(1024) k_roi_stats(const float* __restrict__ fr
 // ------------------------------------------------------------------------------------ product + inverse column pass
 struct ProdArgs {
     const float2* spec_a;   // image half spectra (tile-major), item-indexed
-    const float2* nyq_a;    // (items, NY) Nyquist columns
     const float2* spec_b;   // template half spectra
-    const float2* nyq_b;
     const int* idx_a;       // per pair; null = identity
     const int* idx_b;
     float2* g;              // (pairs) tile-major output of the inverse column pass
@@ -64,53 +62,44 @@ struct ProdArgs {
     unsigned flags;         // B4D_REMOVE_MEAN: zero the DC bin of the product (both means removed)
 };
 
-// c = a * conj(b), optionally whitened: c / (|c| + eps)   (signal/tracking.py:280-281)
-template <bool WHITEN>
-__device__ __forceinline__ float2 cross_power(float2 a, float2 b, float eps) {
-    float2 c = make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
-    if (WHITEN) {
-        const float m = sqrtf(fmaf(c.x, c.x, c.y * c.y)) + eps;
-        c.x /= m;
-        c.y /= m;
-    }
-    return c;
-}
-
-// block CP*NY/16.  TILE0: grid (1, pairs) else (nt-1, pairs).
-template <int NY, int CP, bool TILE0, bool WHITEN>
-__global__ void __launch_bounds__(CP * (NY / E16)) k_col_prod(ProdArgs p) {
-    using G = ColGeom<NY, CP>;
-    constexpr int T = G::T, E = E16, CT = 2 * CP;
+// grid (nt, pairs), block ColCfg<NY>::THREADS (same tile geometry as k_col).
+template <int NY, bool WHITEN>
+__global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col_prod(ProdArgs p) {
+    using Cfg = ColCfg<NY>;
+    using G = typename Cfg::G;
+    constexpr int T = G::T, E = E16, NC = Cfg::NC, CPT = Cfg::CPT, CT = Cfg::CT;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int cp = threadIdx.x % CP, u = threadIdx.x / CP;
-    const int ct = TILE0 ? 0 : blockIdx.x + 1, nt = p.nt;
+    const int cp = threadIdx.x % CPT, u = threadIdx.x / CPT;
+    const int ct = blockIdx.x, nt = gridDim.x;
     const size_t pair = blockIdx.y;
     const size_t ia = p.idx_a ? p.idx_a[pair] : pair, ib = p.idx_b ? p.idx_b[pair] : pair;
     const float2* ta = p.spec_a + ((ia * nt + ct) * (size_t)NY) * CT;
     const float2* tb = p.spec_b + ((ib * nt + ct) * (size_t)NY) * CT;
     float2* tg = p.g + ((pair * nt + ct) * (size_t)NY) * CT;
-    const unsigned toff = (unsigned)u * CT + 2 * cp;
-    const bool packed = TILE0 && cp == 0;
-    float2 va[E], vb[E];
+    const unsigned toff = (unsigned)u * CT + NC * cp;
+    float2 v[NC][E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const float4 qa = *reinterpret_cast<const float4*>(ta + (size_t)(T * j * CT) + toff);
-        const float4 qb = *reinterpret_cast<const float4*>(tb + (size_t)(T * j * CT) + toff);
-        float2 c0 = cross_power<WHITEN>(make_float2(qa.x, qa.y), make_float2(qb.x, qb.y), p.eps);
-        const float2 c1 = cross_power<WHITEN>(make_float2(qa.z, qa.w), make_float2(qb.z, qb.w), p.eps);
-        if (packed) {  // column 0 also carries the Nyquist column: transform C0 + i*Cnyq in one go
-            const int ky = u + T * j;
-            const float2 cn = cross_power<WHITEN>(p.nyq_a[ia * NY + ky], p.nyq_b[ib * NY + ky], p.eps);
-            if (u == 0 && j == 0 && (p.flags & B4D_REMOVE_MEAN)) c0 = make_float2(0.f, 0.f);
-            c0 = make_float2(c0.x - cn.y, c0.y + cn.x);
-        }
-        va[j] = make_float2(c0.y, c0.x);  // (im, re)-swapped: inverse transform with the forward code
-        vb[j] = make_float2(c1.y, c1.x);
-    }
-    Fft3<G, 2>::run(va, vb, u, cp, lds, p.tw);
 #pragma unroll
-    for (int j = 0; j < E; ++j)
-        *reinterpret_cast<float4*>(tg + (size_t)(T * j * CT) + toff) = make_float4(va[j].y, va[j].x, vb[j].y, vb[j].x);
+        for (int h = 0; h < NC / 2; ++h) {
+            const float4 qa = *reinterpret_cast<const float4*>(ta + (size_t)(T * j * CT) + toff + 2 * h);
+            const float4 qb = *reinterpret_cast<const float4*>(tb + (size_t)(T * j * CT) + toff + 2 * h);
+            float2 c0 = cross_power<WHITEN>(make_float2(qa.x, qa.y), make_float2(qb.x, qb.y), p.eps);
+            const float2 c1 = cross_power<WHITEN>(make_float2(qa.z, qa.w), make_float2(qb.z, qb.w), p.eps);
+            if (h == 0 && j == 0 && ct == 0 && cp == 0 && u == 0 && (p.flags & B4D_REMOVE_MEAN))
+                c0 = make_float2(0.f, 0.f);  // DC bin of the cross spectrum (both means removed)
+            v[2 * h][j] = make_float2(c0.y, c0.x);  // (im, re)-swapped: inverse transform with the forward code
+            v[2 * h + 1][j] = make_float2(c1.y, c1.x);
+        }
+    }
+    Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL>(v, u, cp, lds, p.tw);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        float2 c[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) c[k] = make_float2(v[k][j].y, v[k][j].x);
+        store_cols<NC>(tg + (size_t)(T * j * CT) + toff, c);
+    }
 }
 
 // ------------------------------------------------------------------------------------ tracking epilogue
@@ -304,19 +293,17 @@ __global__ void __launch_bounds__(256) k_scale_by_max(float* __restrict__ x, siz
 using namespace b4d;
 
 // ===================================================================================== host
-template <int NY, int CP, bool TILE0, bool WHITEN>
-static int launch_prod1(const ProdArgs& a, int gx, int pairs, hipStream_t st) {
-    using G = ColGeom<NY, CP>;
-    const size_t lds = sizeof(float2) * (size_t)G::LDS_ELEMS * CP;
+template <int NY, bool WHITEN>
+static int launch_prod(const ProdArgs& a, int nt, int pairs, hipStream_t st) {
+    using Cfg = ColCfg<NY>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col_prod<NY, CP, TILE0, WHITEN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col_prod<NY, WHITEN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     });
     B4D_HIP(attr_err);
-    if (gx < 1) return B4D_OK;
-    hipLaunchKernelGGL((k_col_prod<NY, CP, TILE0, WHITEN>), dim3(gx, pairs), dim3(CP * (NY / E16)), lds, st, a);
+    hipLaunchKernelGGL((k_col_prod<NY, WHITEN>), dim3(nt, pairs), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
@@ -324,62 +311,32 @@ template <bool WHITEN>
 static int dispatch_prod(const b4d_plan* pl, ProdArgs a, int pairs, hipStream_t st) {
     const int nt = (pl->nx / 2) / pl->ct_w;
     a.nt = nt;
-    int rc = B4D_OK;
-#define B4D_PROD_CASE(NY, CP)                                                     \
-    case NY:                                                                      \
-        rc = launch_prod1<NY, CP, false, WHITEN>(a, nt - 1, pairs, st);           \
-        if (rc == B4D_OK) rc = launch_prod1<NY, CP, true, WHITEN>(a, 1, pairs, st); \
-        return rc;
     switch (pl->ny) {
-        B4D_PROD_CASE(64, 8)
-        B4D_PROD_CASE(128, 8)
-        B4D_PROD_CASE(256, 8)
-        B4D_PROD_CASE(512, 8)
-        B4D_PROD_CASE(1024, 8)
-        B4D_PROD_CASE(2048, 8)
-        B4D_PROD_CASE(4096, 4)
+        case 64: return launch_prod<64, WHITEN>(a, nt, pairs, st);
+        case 128: return launch_prod<128, WHITEN>(a, nt, pairs, st);
+        case 256: return launch_prod<256, WHITEN>(a, nt, pairs, st);
+        case 512: return launch_prod<512, WHITEN>(a, nt, pairs, st);
+        case 1024: return launch_prod<1024, WHITEN>(a, nt, pairs, st);
+        case 2048: return launch_prod<2048, WHITEN>(a, nt, pairs, st);
+        case 4096: return launch_prod<4096, WHITEN>(a, nt, pairs, st);
     }
-#undef B4D_PROD_CASE
     return fail(B4D_ESIZE, "unsupported ny");
 }
 
-template <int NX>
-static int launch_c2r_mode(const b4d_plan* pl, const RowOutArgs& a, int batch, bool mag, hipStream_t st, int* nblk) {
-    constexpr int SEQ = row_seq(NX);
-    const dim3 grid((pl->ny / 2 + SEQ - 1) / SEQ, batch), block((NX / E16) * SEQ);
-    if (nblk) *nblk = grid.x;
-    if (batch < 1) return B4D_OK;
-    if (mag)
-        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_MAG>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_OUT>), grid, block, 0, st, a);
-    B4D_HIP(hipGetLastError());
-    return B4D_OK;
-}
-static int dispatch_c2r_mode(const b4d_plan* pl, const RowOutArgs& a, int batch, bool mag, hipStream_t st, int* nblk) {
-    switch (pl->nx) {
-        case 64: return launch_c2r_mode<64>(pl, a, batch, mag, st, nblk);
-        case 128: return launch_c2r_mode<128>(pl, a, batch, mag, st, nblk);
-        case 256: return launch_c2r_mode<256>(pl, a, batch, mag, st, nblk);
-        case 512: return launch_c2r_mode<512>(pl, a, batch, mag, st, nblk);
-        case 1024: return launch_c2r_mode<1024>(pl, a, batch, mag, st, nblk);
-        case 2048: return launch_c2r_mode<2048>(pl, a, batch, mag, st, nblk);
-        case 4096: return launch_c2r_mode<4096>(pl, a, batch, mag, st, nblk);
-    }
-    return fail(B4D_ESIZE, "unsupported nx");
-}
-
-// forward 2-D half spectra of `items` sources into spec (tile-major) + nyq (items, ny)
+// forward 2-D half spectra of `items` sources into spec (tile-major) + nyq (items, ny) complex
 static int forward_spectra(const b4d_plan* pl, const float* frames, const RowSrc* srcs, int items, float2* spec,
-                           float2* nyq, hipStream_t st) {
-    int rc = dispatch_r2c(pl, frames, items, st, spec, srcs);
+                           float* nyq_rows, float2* nyq, hipStream_t st) {
+    int rc = dispatch_r2c(pl, frames, items, st, spec, nyq_rows, srcs);
     if (rc) return rc;
     ColArgs ca{};
     ca.spec = spec;
-    ca.full = nyq;
     ca.tw = pl->tw_y;
     ca.nx = pl->nx;
-    return dispatch_col<COL_FORWARD>(pl, ca, items, st);
+    if ((rc = dispatch_col<COL_FORWARD>(pl, ca, items, st))) return rc;
+    NyqArgs na{};
+    na.rows = nyq_rows;
+    na.f_out = nyq;
+    return dispatch_nyq<NYQ_FORWARD>(pl, na, items, st);
 }
 
 namespace {
@@ -412,48 +369,73 @@ static int track_arena(b4d_plan* pl, size_t bytes, Arena* a) {
     return B4D_OK;
 }
 
+// Fi * conj(Ft) [whitened] -> inverse column pass (tiles + Nyquist column) for `pairs` pairs
+template <bool WHITEN>
+static int product_inverse(const b4d_plan* pl, const float2* spec, const float2* nyq, const int* idx_a, const int* idx_b,
+                           const float2* spec_b, const float2* nyq_b, int pairs, float2* g, float* gnyq, float eps,
+                           unsigned flags, hipStream_t st) {
+    ProdArgs pa{};
+    pa.spec_a = spec;
+    pa.spec_b = spec_b;
+    pa.idx_a = idx_a;
+    pa.idx_b = idx_b;
+    pa.g = g;
+    pa.tw = pl->tw_y;
+    pa.eps = eps;
+    pa.flags = flags;
+    int rc = dispatch_prod<WHITEN>(pl, pa, pairs, st);
+    if (rc) return rc;
+    NyqArgs na{};
+    na.fa = nyq;
+    na.fb = nyq_b;
+    na.idx_a = idx_a;
+    na.idx_b = idx_b;
+    na.g_out = gnyq;
+    na.eps = eps;
+    return dispatch_nyq<WHITEN ? NYQ_PROD_WHITEN : NYQ_PROD>(pl, na, pairs, st);
+}
+
 extern "C" {
 
 int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, void* stream) {
     if (!pl || !a || !b || !corr) return fail(B4D_EINVAL, "null argument");
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
     hipStream_t st = (hipStream_t)stream;
-    const size_t fpix = (size_t)pl->ny * pl->nx, half = fpix / 2;
+    const size_t fpix = (size_t)pl->ny * pl->nx, half = fpix / 2, ny = pl->ny;
     const int chunk = pl->chunk;
+    size_t need = 0;
+    auto add = [&](size_t bytes) { need += ((bytes + 255) & ~(size_t)255) + 256; };
+    for (int i = 0; i < 3; ++i) add(sizeof(float2) * half * chunk);
+    for (int i = 0; i < 2; ++i) add(sizeof(float2) * ny * chunk);
+    for (int i = 0; i < 3; ++i) add(sizeof(float) * ny * chunk);
+    add(sizeof(float) * 256 * chunk);
     Arena ar;
-    const size_t need = 3 * (sizeof(float2) * half * chunk + 256) + 2 * (sizeof(float2) * pl->ny * chunk + 256) +
-                        2 * sizeof(RowSrc) * chunk + 512 + sizeof(float) * 256 * chunk + 256;
     int rc = track_arena(pl, need, &ar);
     if (rc) return rc;
     float2* sa = ar.take<float2>(half * chunk);
     float2* sb = ar.take<float2>(half * chunk);
     float2* g = ar.take<float2>(half * chunk);
-    float2* na = ar.take<float2>((size_t)pl->ny * chunk);
-    float2* nb_ = ar.take<float2>((size_t)pl->ny * chunk);
+    float2* fa = ar.take<float2>(ny * chunk);
+    float2* fb = ar.take<float2>(ny * chunk);
+    float* ra_rows = ar.take<float>(ny * chunk);
+    float* rb_rows = ar.take<float>(ny * chunk);
+    float* gnyq = ar.take<float>(ny * chunk);
     float* part = ar.take<float>((size_t)256 * chunk);
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = std::min(chunk, batch - b0);
-        if ((rc = forward_spectra(pl, a + b0 * fpix, nullptr, nb, sa, na, st))) return rc;
-        if ((rc = forward_spectra(pl, b + b0 * fpix, nullptr, nb, sb, nb_, st))) return rc;
-        ProdArgs pa{};
-        pa.spec_a = sa;
-        pa.nyq_a = na;
-        pa.spec_b = sb;
-        pa.nyq_b = nb_;
-        pa.g = g;
-        pa.tw = pl->tw_y;
-        pa.eps = 0.f;
-        pa.flags = flags;
-        if ((rc = dispatch_prod<false>(pl, pa, nb, st))) return rc;
+        if ((rc = forward_spectra(pl, a + b0 * fpix, nullptr, nb, sa, ra_rows, fa, st))) return rc;
+        if ((rc = forward_spectra(pl, b + b0 * fpix, nullptr, nb, sb, rb_rows, fb, st))) return rc;
+        if ((rc = product_inverse<false>(pl, sa, fa, nullptr, nullptr, sb, fb, nb, g, gnyq, 0.f, flags, st))) return rc;
         RowOutArgs ra{};
         ra.g = g;
+        ra.gnyq = gnyq;
         ra.out = corr + b0 * fpix;
         ra.tw = pl->tw_x;
         ra.scale = 1.0f / ((float)pl->nx * (float)pl->ny);
         ra.ny = pl->ny;
         ra.ct_w = pl->ct_w;
         ra.flags = 0;
-        if ((rc = dispatch_c2r_mode(pl, ra, nb, false, st, nullptr))) return rc;
+        if ((rc = dispatch_c2r(pl, ra, nb, st, C2R_OUT))) return rc;
         if (flags & B4D_NORM_PEAK) {
             hipLaunchKernelGGL(k_absmax_part, dim3(256, nb), dim3(1024), 0, st, corr + b0 * fpix, fpix, part);
             hipLaunchKernelGGL(k_scale_by_max, dim3(1024, nb), dim3(256), 0, st, corr + b0 * fpix, fpix, part, 256);
@@ -487,10 +469,12 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     size_t need = 0;
     auto add = [&](size_t b) { need += ((b + 255) & ~(size_t)255) + 256; };
     add(sizeof(float2) * half * nsrc);        // spectra
-    add(sizeof(float2) * (size_t)ny * nsrc);  // nyquist columns
+    add(sizeof(float2) * (size_t)ny * nsrc);  // Nyquist column spectra
+    add(sizeof(float) * (size_t)ny * nsrc);   // Nyquist bins after the row pass
     add(sizeof(RowSrc) * nsrc);
     add(sizeof(int) * 2 * (size_t)npairs);
     add(sizeof(float2) * half * pc);          // G
+    add(sizeof(float) * (size_t)ny * pc);     // G of the Nyquist column
     add(sizeof(float) * fpix * pc);           // magnitude maps
     add(sizeof(float) * 2048 * (size_t)pc);
     add(sizeof(int) * 2048 * (size_t)pc);
@@ -499,9 +483,11 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     if (rc) return rc;
     float2* spec = ar.take<float2>(half * nsrc);
     float2* nyq = ar.take<float2>((size_t)ny * nsrc);
+    float* nyq_rows = ar.take<float>((size_t)ny * nsrc);
     RowSrc* srcs = ar.take<RowSrc>(nsrc);
     int* pidx = ar.take<int>(2 * (size_t)npairs);
     float2* g = ar.take<float2>(half * pc);
+    float* gnyq = ar.take<float>((size_t)ny * pc);
     float* mag = ar.take<float>(fpix * pc);
     float* pval = ar.take<float>((size_t)2048 * pc);
     int* pind = ar.take<int>((size_t)2048 * pc);
@@ -526,30 +512,25 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     const int fc = std::max(1, pl->chunk * 2);
     for (int i0 = 0; i0 < nimg; i0 += fc) {
         const int n = std::min(fc, nimg - i0);
-        if ((rc = forward_spectra(pl, images, srcs + i0, n, spec + half * i0, nyq + (size_t)ny * i0, st))) return rc;
+        if ((rc = forward_spectra(pl, images, srcs + i0, n, spec + half * i0, nyq_rows + (size_t)ny * i0,
+                                  nyq + (size_t)ny * i0, st)))
+            return rc;
     }
     for (int k0 = 0; k0 < ntpl; k0 += fc) {
-        const int n = std::min(fc, ntpl - k0);
-        if ((rc = forward_spectra(pl, tpl_src, srcs + nimg + k0, n, spec + half * (nimg + k0),
-                                  nyq + (size_t)ny * (nimg + k0), st)))
+        const int n = std::min(fc, ntpl - k0), o = nimg + k0;
+        if ((rc = forward_spectra(pl, tpl_src, srcs + o, n, spec + half * o, nyq_rows + (size_t)ny * o,
+                                  nyq + (size_t)ny * o, st)))
             return rc;
     }
     // ---- pairs
     for (int p0 = 0; p0 < npairs; p0 += pc) {
         const int np = std::min(pc, npairs - p0);
-        ProdArgs pa{};
-        pa.spec_a = spec;
-        pa.nyq_a = nyq;
-        pa.spec_b = spec;
-        pa.nyq_b = nyq;
-        pa.idx_a = pidx + p0;
-        pa.idx_b = pidx + npairs + p0;
-        pa.g = g;
-        pa.tw = pl->tw_y;
-        pa.eps = (float)eps;
-        if ((rc = dispatch_prod<true>(pl, pa, np, st))) return rc;
+        if ((rc = product_inverse<true>(pl, spec, nyq, pidx + p0, pidx + npairs + p0, spec, nyq, np, g, gnyq, (float)eps,
+                                        0u, st)))
+            return rc;
         RowOutArgs ra{};
         ra.g = g;
+        ra.gnyq = gnyq;
         ra.out = mag;
         ra.tw = pl->tw_x;
         ra.scale = 1.0f / ((float)nx * (float)ny);
@@ -558,7 +539,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         ra.part_val = pval;
         ra.part_idx = pind;
         int nblk = 0;
-        if ((rc = dispatch_c2r_mode(pl, ra, np, true, st, &nblk))) return rc;
+        if ((rc = dispatch_c2r(pl, ra, np, st, C2R_MAG, nullptr, &nblk))) return rc;
         FinArgs fa{};
         fa.mag = mag;
         fa.part_val = pval;
