@@ -176,19 +176,26 @@ struct Fft3 {
         }
     }
     // exchange 1: addr1(k2, n1) = k2*S1 + n1 ; stage-2 combos c = k2 + R1*m1, lane u handles c = u + T*i2
-    static __device__ __forceinline__ void xchg1(float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
-        constexpr int B1 = E / R1, B2 = E / R2;
+    static __device__ __forceinline__ void xchg1_write(const float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
+        constexpr int B1 = E / R1;
 #pragma unroll
         for (int i = 0; i < B1; ++i)
 #pragma unroll
             for (int k2 = 0; k2 < R1; ++k2) lds[(k2 * G::S1 + u + T * i) * CI + ci] = v[i + B1 * k2];
-        __syncthreads();
+    }
+    static __device__ __forceinline__ void xchg1_read(float2 (&v)[E], int u, int ci, const float2* __restrict__ lds) {
+        constexpr int B2 = E / R2;
 #pragma unroll
         for (int i2 = 0; i2 < B2; ++i2) {
             const int c = u + T * i2, k2 = c % R1, m1 = c / R1;
 #pragma unroll
             for (int m2 = 0; m2 < R2; ++m2) v[i2 + B2 * m2] = lds[(k2 * G::S1 + m1 + R3 * m2) * CI + ci];
         }
+    }
+    static __device__ __forceinline__ void xchg1(float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
+        xchg1_write(v, u, ci, lds);
+        __syncthreads();
+        xchg1_read(v, u, ci, lds);
     }
     // stage 2: DFT over m2, twiddle w_M^(m1*q2) = w_N^(R1*m1*q2)
     static __device__ __forceinline__ void stage2(float2 (&v)[E], int u, const float2* __restrict__ tw) {
@@ -202,19 +209,26 @@ struct Fft3 {
         }
     }
     // exchange 2: addr2(q2, m1, k2) = q2*S2 + c ; stage-3 butterflies A = k2 + R1*q2, lane u handles A = u + T*a
-    static __device__ __forceinline__ void xchg2(float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
-        constexpr int B2 = E / R2, B3 = E / R3;
+    static __device__ __forceinline__ void xchg2_write(const float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
+        constexpr int B2 = E / R2;
 #pragma unroll
         for (int i2 = 0; i2 < B2; ++i2)
 #pragma unroll
             for (int q2 = 0; q2 < R2; ++q2) lds[(q2 * G::S2 + u + T * i2) * CI + ci] = v[i2 + B2 * q2];
-        __syncthreads();
+    }
+    static __device__ __forceinline__ void xchg2_read(float2 (&v)[E], int u, int ci, const float2* __restrict__ lds) {
+        constexpr int B3 = E / R3;
 #pragma unroll
         for (int a = 0; a < B3; ++a) {
             const int A = u + T * a, k2 = A % R1, q2 = A / R1;
 #pragma unroll
             for (int m1 = 0; m1 < R3; ++m1) v[a + B3 * m1] = lds[(q2 * G::S2 + m1 * R1 + k2) * CI + ci];
         }
+    }
+    static __device__ __forceinline__ void xchg2(float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
+        xchg2_write(v, u, ci, lds);
+        __syncthreads();
+        xchg2_read(v, u, ci, lds);
     }
     // stage 3: outputs q1 -> register a + B3*q1  <->  k = u + T*(a + B3*q1)
     static __device__ __forceinline__ void stage3(float2 (&v)[E]) { butterflies<R3, E / R3, E / R3>(v); }
@@ -262,9 +276,42 @@ struct Fft3 {
     // Same entry/exit contract as run().  SERIAL pins the per-set order with sched_barriers (only
     // useful when the kernel sits at its VGPR cap); otherwise the compiler may overlap set s+1's
     // butterflies with set s's LDS round trip.
-    template <int NS, bool SERIAL, bool WITH_STAGE3 = true>
+    // SB > 1: SB sets go through the buffer TOGETHER (the buffer holds SB regions of SET_ELEMS complex
+    // values): half the barriers and twice the independent work between them.
+    template <int NS, bool SERIAL, bool WITH_STAGE3 = true, int SB = 1>
     static __device__ __forceinline__ void run_sets(float2 (&v)[NS][E], int u, int ci, float2* __restrict__ lds,
                                                     const float2* __restrict__ tw) {
+        if (SB > 1) {
+            static_assert(NS % SB == 0, "batch must divide the set count");
+            constexpr int SET_ELEMS = G::LDS_ELEMS * CI;
+#pragma unroll
+            for (int b = 0; b < NS; b += SB) {
+#pragma unroll
+                for (int s = 0; s < SB; ++s) stage1(v[b + s], u, tw);
+                if (b > 0) __syncthreads();
+#pragma unroll
+                for (int s = 0; s < SB; ++s) xchg1_write(v[b + s], u, ci, lds + s * SET_ELEMS);
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < SB; ++s) xchg1_read(v[b + s], u, ci, lds + s * SET_ELEMS);
+            }
+#pragma unroll
+            for (int b = 0; b < NS; b += SB) {
+#pragma unroll
+                for (int s = 0; s < SB; ++s) stage2(v[b + s], u, tw);
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < SB; ++s) xchg2_write(v[b + s], u, ci, lds + s * SET_ELEMS);
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < SB; ++s) xchg2_read(v[b + s], u, ci, lds + s * SET_ELEMS);
+            }
+            if (WITH_STAGE3) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) stage3(v[s]);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             stage1(v[s], u, tw);

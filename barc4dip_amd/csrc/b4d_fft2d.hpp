@@ -148,7 +148,26 @@ struct ColArgs {
     float psd_scale;
     int nx;
     unsigned flags;
+#ifdef B4D_DIAG
+    unsigned long long* diag;  // diagnostic build only: 8 s_memtime stamps per workgroup
+#endif
 };
+
+#ifdef B4D_DIAG
+// Diagnostic build (never shipped, never timed as a whole): phase stamps of wave 0 of each workgroup.
+#define B4D_STAMP(i)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t__;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");              \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (p.diag && threadIdx.x == 0) p.diag[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = t__; \
+    } while (0)
+#define B4D_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define B4D_STAMP(i) do {} while (0)
+#define B4D_DRAIN() do {} while (0)
+#endif
 
 // Column-tile geometry: a lane holds NC adjacent columns (NC*8 bytes per row), CPT lanes span the tile
 // (CT = NC*CPT columns = whole 128-B lines per row), T = NY/16 lanes run along y.
@@ -162,7 +181,9 @@ struct ColCfg {
     static constexpr int CT = NC * CPT;
     static constexpr int THREADS = CPT * (NY / E16);
     using G = ColGeom<NY, CPT>;
-    static constexpr size_t LDS_BYTES = sizeof(float2) * (size_t)G::LDS_ELEMS * CPT;
+    // sets that share one LDS round trip: 2 wherever two exchange regions fit in the 160 KiB
+    static constexpr int SB = (2 * sizeof(float2) * (size_t)G::LDS_ELEMS * CPT <= 160 * 1024 && NC >= 4) ? 2 : 1;
+    static constexpr size_t LDS_BYTES = sizeof(float2) * (size_t)G::LDS_ELEMS * CPT * SB;
     static constexpr bool SERIAL = THREADS > 512;  // at the 128-VGPR cap: pin the per-set order
 };
 
@@ -196,6 +217,7 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
     float2* tile = p.spec + ((frame * nt + ct) * (size_t)NY) * CT;
     const unsigned toff = (unsigned)u * CT + NC * cp;  // element offset of (row u, first column of this lane)
     float2 v[NC][E];
+    B4D_STAMP(0);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
 #pragma unroll
@@ -205,7 +227,10 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
             v[2 * h + 1][j] = make_float2(q.z, q.w);
         }
     }
-    Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL, MODE != COL_PSD_AC>(v, u, cp, lds, p.tw);
+    B4D_DRAIN();
+    B4D_STAMP(1);
+    Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL, MODE != COL_PSD_AC, Cfg::SB>(v, u, cp, lds, p.tw);
+    B4D_STAMP(2);
     // v[c][j] = F[ky = u + T j][kx0 + c]   (COL_PSD_AC: after the stage-3 butterflies done below)
     const int kx0 = ct * CT + NC * cp;
 
@@ -285,6 +310,9 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
             for (int h = 0; h < NC / 2; ++h) w[h][j] = make_float2(pw[2 * h + 1], pw[2 * h]);
         }
     }
+    B4D_STAMP(3);
+    B4D_DRAIN();
+    B4D_STAMP(4);
     if (kx0 == 0 && u == 0 && (p.flags & B4D_REMOVE_MEAN)) w[0][0].y = 0.f;  // DC bin: ky = 0 <-> u = 0, j = 0
     // Launder pointer/offset: otherwise the compiler keeps the first transform's twiddles and the 64-bit
     // load addresses alive across the whole kernel (provably identical loads / addresses).
@@ -293,17 +321,23 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
     unsigned toff2 = toff;
     asm volatile("" : "+v"(toff2));
     __syncthreads();
-    Fft3<G, 1>::template run_sets<NC / 2, Cfg::SERIAL>(w, u, cp, lds, tw2);
+    Fft3<G, 1>::template run_sets<NC / 2, Cfg::SERIAL, true, Cfg::SB>(w, u, cp, lds, tw2);
+    B4D_STAMP(5);
     // V[y] = Ga[y] + i Gb[y] with Ga, Gb Hermitian in y: split with V[-y], one set at a time
     float2 vr[NC / 2][E];
+    constexpr int SETE = G::LDS_ELEMS * CPT;  // one exchange region (complex elements)
 #pragma unroll
-    for (int h = 0; h < NC / 2; ++h) {
+    for (int b = 0; b < NC / 2; b += Cfg::SB) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < E; ++j) lds[(u + T * j) * CPT + cp] = make_float2(w[h][j].y, w[h][j].x);
+        for (int h = b; h < b + Cfg::SB; ++h)
+#pragma unroll
+            for (int j = 0; j < E; ++j) lds[(h - b) * SETE + (u + T * j) * CPT + cp] = make_float2(w[h][j].y, w[h][j].x);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < E; ++j) vr[h][j] = lds[((NY - (u + T * j)) & (NY - 1)) * CPT + cp];
+        for (int h = b; h < b + Cfg::SB; ++h)
+#pragma unroll
+            for (int j = 0; j < E; ++j) vr[h][j] = lds[(h - b) * SETE + ((NY - (u + T * j)) & (NY - 1)) * CPT + cp];
     }
 #pragma unroll
     for (int j = 0; j < E; ++j) {
@@ -316,6 +350,9 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
         }
         store_cols<NC>(tile + (size_t)(T * j * CT) + toff2, c);
     }
+    B4D_STAMP(6);
+    B4D_DRAIN();
+    B4D_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------ Nyquist column

@@ -61,6 +61,11 @@ int b4d_plan_destroy(b4d_plan* p) {
 
 size_t b4d_plan_workspace_bytes(const b4d_plan* p) { return p ? p->ws_bytes : 0; }
 
+#ifdef B4D_DIAG
+static unsigned long long* g_diag = nullptr;
+extern "C" void b4d_debug_set_diag(void* buf) { g_diag = static_cast<unsigned long long*>(buf); }
+#endif
+
 // Shared body.  With `kernel_ms` != null every kernel launch is bracketed by HIP events on `st`
 // and the per-kernel elapsed times (ms; row R2C, column, peak, row C2R) are ADDED to kernel_ms[0..3]
 // after a final hipEventSynchronize -- used by bench.py to price each kernel inside its timed region.
@@ -92,6 +97,9 @@ static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float
         ca.psd_scale = psd_scale;
         ca.nx = pl->nx;
         ca.flags = flags;
+#ifdef B4D_DIAG
+        ca.diag = g_diag;
+#endif
         if ((rc = dispatch_col<COL_PSD_AC>(pl, ca, nb, st))) break;
         NyqArgs na{};
         na.rows = pl->nyq_rows;

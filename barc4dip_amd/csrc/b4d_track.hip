@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col_prod(ProdArgs p) {
             v[2 * h + 1][j] = make_float2(c1.y, c1.x);
         }
     }
-    Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL>(v, u, cp, lds, p.tw);
+    Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL, true, Cfg::SB>(v, u, cp, lds, p.tw);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         float2 c[NC];

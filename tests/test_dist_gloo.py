@@ -1,0 +1,55 @@
+"""CPU tier: the N > 1 path of the temporal statistics (frame-wise sharding + ONE all-reduce of the
+float64 sums) with world_size 2 and 3 over gloo.  The device kernels are replaced by their oracle
+restatement here (this tier has no GPU); the collective and the sharding are the product's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from barc4dip_amd import synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from barc4dip_amd.metrics.temporal import reduce_sums_cpu, shard_bounds
+    from oracle import temporal_np as Tn
+
+    stack = synth.speckle_stack(total, 64, seed0=900)
+    t0, t1 = shard_bounds(total, world, rank)
+    sx, sxx, n = Tn.temporal_sums(stack[t0:t1]) if t1 > t0 else (np.zeros((64, 64)), np.zeros((64, 64)), 0)
+    gx, gxx, cnt = reduce_sums_cpu(sx, sxx, n)
+    mean, var, con = Tn.finalize_sums(gx, gxx, cnt)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), mean=mean, var=var, con=con, cnt=cnt)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(2, 11), (3, 7)])
+def test_sharded_temporal_stats_equal_single_rank(tmp_path, world, total):
+    from oracle import temporal_np as Tn
+
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    stack = synth.speckle_stack(total, 64, seed0=900)
+    rm, rv, rc = Tn.temporal_stats(stack)
+    for r in range(world):
+        g = np.load(tmp_path / f"r{r}.npz")
+        assert float(g["cnt"]) == total
+        np.testing.assert_allclose(g["mean"], rm, rtol=1e-14)
+        np.testing.assert_allclose(g["var"], rv, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(g["con"], rc, rtol=1e-9)
+    a, b = np.load(tmp_path / "r0.npz"), np.load(tmp_path / f"r{world - 1}.npz")
+    assert np.array_equal(a["mean"], b["mean"]) and np.array_equal(a["var"], b["var"])   # every rank holds the same bits
