@@ -14,6 +14,7 @@
 
 #include "../../include/b4d.h"
 #include "b4d_common.hpp"
+#include "b4d_select.hpp"
 
 namespace b4d {
 
@@ -303,6 +304,235 @@ __global__ void __launch_bounds__(256) k_sobel_fin(const double* __restrict__ pa
     }
 }
 
+
+// ------------------------------------------------------------------------------------ percentiles
+// np.nanpercentile(x, q) with the default linear interpolation (utils/range.py:44-54): for each q the two
+// bracketing order statistics are selected exactly; out = {lo value, hi value, fraction, n_valid} and the
+// caller finishes lo + (hi - lo) * t in float64 exactly like NumPy's _lerp.   grid (batch), block 1024.
+__global__ void __launch_bounds__(1024) k_percentiles(const float* __restrict__ frames, size_t npix, const double* __restrict__ q,
+                                                      int nq, double* __restrict__ out) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned sh[4];
+    __shared__ unsigned s_cnt[16];
+    const float* x = frames + (size_t)blockIdx.x * npix;
+    const unsigned n_all = (unsigned)npix;
+    unsigned c = 0;
+    for (unsigned i = threadIdx.x; i < n_all; i += blockDim.x) c += (x[i] == x[i]) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    unsigned n = 0;
+    for (int i = 0; i < 16; ++i) n += s_cnt[i];
+    __syncthreads();
+    for (int iq = 0; iq < nq; ++iq) {
+        double* o = out + ((size_t)blockIdx.x * nq + iq) * 4;
+        if (n == 0) {
+            if (threadIdx.x == 0) o[0] = o[1] = nan(""), o[2] = 0.0, o[3] = 0.0;
+            continue;
+        }
+        const double pos = q[iq] / 100.0 * (double)(n - 1);
+        unsigned lo = (unsigned)floor(pos);
+        if (lo > n - 1) lo = n - 1;
+        const unsigned hi = lo + 1 < n ? lo + 1 : n - 1;
+        unsigned nl, ne;
+        const unsigned ka = radix_select(x, n_all, lo, hist, sh, nl, ne);
+        unsigned kb = ka;
+        if (hi != lo && nl + ne <= hi) kb = next_larger_key(x, n_all, ka, hist);
+        if (threadIdx.x == 0) {
+            o[0] = (double)key2f(ka);
+            o[1] = (double)key2f(kb);
+            o[2] = pos - (double)lo;
+            o[3] = (double)n;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------ radial profile
+// maths/radial.py:101-169 radial_mean_interpolated: r = linspace(0, r_max, nr), theta = linspace(0, 2pi, ntheta,
+// endpoint=False), bilinear RegularGridInterpolator on the pixel-centre grid (x = j - nx//2), fill 0 outside,
+// mean over theta.  grid (nr, batch), block 256.
+__global__ void __launch_bounds__(256) k_radial_profile(const float* __restrict__ maps, int ny, int nx, int nr, int ntheta,
+                                                        double r_max, double* __restrict__ out) {
+    __shared__ double sh[4];
+    const float* z = maps + (size_t)blockIdx.y * ny * nx;
+    const int ir = blockIdx.x;
+    const double r = nr > 1 ? (ir == nr - 1 ? r_max : (double)ir * (r_max / (double)(nr - 1))) : 0.0;
+    const double x0 = -(double)(nx / 2), x1 = (double)(nx - 1 - nx / 2), y0 = -(double)(ny / 2), y1 = (double)(ny - 1 - ny / 2);
+    const double two_pi = 6.283185307179586476925286766559;
+    double acc = 0.0;
+    for (int it = threadIdx.x; it < ntheta; it += blockDim.x) {
+        const double th = (double)it * (two_pi / (double)ntheta);
+        const double px = r * cos(th), py = r * sin(th);
+        double val = 0.0;
+        if (px >= x0 && px <= x1 && py >= y0 && py <= y1) {
+            const double fx = px - x0, fy = py - y0;  // index space
+            int jx = (int)floor(fx), jy = (int)floor(fy);
+            jx = jx > nx - 2 ? nx - 2 : jx;
+            jy = jy > ny - 2 ? ny - 2 : jy;
+            const double tx = fx - (double)jx, ty = fy - (double)jy;
+            const float* p = z + (size_t)jy * nx + jx;
+            const double v00 = p[0], v01 = p[1], v10 = p[nx], v11 = p[nx + 1];
+            val = (1.0 - ty) * ((1.0 - tx) * v00 + tx * v01) + ty * ((1.0 - tx) * v10 + tx * v11);
+        }
+        acc += val;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(size_t)blockIdx.y * nr + ir] = (sh[0] + sh[1] + sh[2] + sh[3]) / (double)ntheta;
+}
+
+// ------------------------------------------------------------------------------------ PSD statistics
+// metrics/speckles.py:669-817 (bandwidth) and metrics/sharpness.py:536-629 (spectral entropy) from ONE shifted
+// PSD map whose DC bin is treated as zero (both functions remove the mean and zero the DC bin):
+//   sums over the inscribed frequency disc FR <= min(max|fx|, max|fy|): S, sum FR^2 P, sum FX^2 P, sum FY^2 P, sum P^2
+//   sum over ALL bins: S_all, and sum P ln P (entropy follows as ln S_all - sum(P ln P)/S_all)
+//   f95: radius where the radius-ordered cumulative power reaches 0.95 S (two histogram passes: coarse integer
+//        radius, then the exact r^2 values inside that ring) -- square maps only.
+struct PsdStatArgs {
+    const float* psd;
+    int ny, nx, nblk;
+    double* part;     // [batch][nblk][8]
+    double* coarse;   // [batch][ncoarse]
+    double* fine;     // [batch][nfine]
+    const int* ring;  // [batch] coarse ring index (pass 2)
+    int ncoarse, nfine;
+};
+
+__device__ __forceinline__ void psd_coords(int i, int j, int ny, int nx, double& fx, double& fy, long long& r2) {
+    const int dy = i - ny / 2, dx = j - nx / 2;
+    fx = (double)dx / (double)nx;
+    fy = (double)dy / (double)ny;
+    r2 = (long long)dx * dx + (long long)dy * dy;
+}
+
+// pass 1: partial sums + coarse radial histogram (bin = floor(sqrt(r2)), square maps).  grid (nblk, batch), block 256
+__global__ void __launch_bounds__(256) k_psd_stats1(PsdStatArgs a, double fmax) {
+    __shared__ double sh[16 * 7];
+    extern __shared__ double lhist[];  // ncoarse
+    const float* P = a.psd + (size_t)blockIdx.y * a.ny * a.nx;
+    for (int i = threadIdx.x; i < a.ncoarse; i += blockDim.x) lhist[i] = 0.0;
+    __syncthreads();
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    const size_t n = (size_t)a.ny * a.nx;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / a.nx), j = (int)(e % a.nx);
+        double p = (double)P[e];
+        if (i == a.ny / 2 && j == a.nx / 2) p = 0.0;
+        if (!isfinite(p)) p = 0.0;  // np.nan_to_num(..., 0)
+        double fx, fy;
+        long long r2;
+        psd_coords(i, j, a.ny, a.nx, fx, fy, r2);
+        const double fr2 = __dadd_rn(__dmul_rn(fx, fx), __dmul_rn(fy, fy));
+        const double fr = sqrt(fr2);
+        v[5] += p;
+        if (p > 0.0) v[6] = fma(p, log(p), v[6]);
+        if (fr <= fmax) {
+            v[0] += p;
+            v[1] = fma(__dmul_rn(fr, fr), p, v[1]);
+            v[2] = fma(__dmul_rn(fx, fx), p, v[2]);
+            v[3] = fma(__dmul_rn(fy, fy), p, v[3]);
+            v[4] = fma(p, p, v[4]);
+            if (a.ncoarse > 0) {
+                int b = (int)floor(sqrt((double)r2));
+                b = b < a.ncoarse ? b : a.ncoarse - 1;
+                atomicAdd(&lhist[b], p);
+            }
+        }
+    }
+    block_sum<7>(v, sh);
+    if (threadIdx.x == 0) {
+        double* o = a.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = v[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.ncoarse; i += blockDim.x)
+        if (lhist[i] != 0.0) atomicAdd(&a.coarse[(size_t)blockIdx.y * a.ncoarse + i], lhist[i]);
+}
+
+// reduce partials -> out[b][0..6]; pick the coarse ring where the cumulative power crosses 0.95 S.  grid (batch), block 64
+__global__ void k_psd_stats_mid(PsdStatArgs a, double* __restrict__ out, int* __restrict__ ring, double* __restrict__ below) {
+    if (threadIdx.x != 0) return;
+    const int b = blockIdx.x;
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < a.nblk; ++i)
+        for (int k = 0; k < 7; ++k) v[k] += a.part[((size_t)b * a.nblk + i) * 8 + k];
+    for (int k = 0; k < 7; ++k) out[(size_t)b * 8 + k] = v[k];
+    int r = a.ncoarse - 1;
+    double cum = 0.0;
+    if (a.ncoarse > 0) {
+        double tot = 0.0;
+        for (int i = 0; i < a.ncoarse; ++i) tot += a.coarse[(size_t)b * a.ncoarse + i];
+        for (int i = 0; i < a.ncoarse; ++i) {
+            const double c = a.coarse[(size_t)b * a.ncoarse + i];
+            if ((cum + c) / tot >= 0.95) {
+                r = i;
+                break;
+            }
+            cum += c;
+        }
+        out[(size_t)b * 8 + 7] = tot;  // masked total as accumulated by the histogram (diagnostic)
+    }
+    ring[b] = r;
+    below[b] = cum;
+}
+
+// pass 2: exact r^2 histogram inside the selected ring [R^2, (R+1)^2).  grid (nblk, batch), block 256
+__global__ void __launch_bounds__(256) k_psd_stats2(PsdStatArgs a, double fmax) {
+    extern __shared__ double lhist[];  // nfine
+    const float* P = a.psd + (size_t)blockIdx.y * a.ny * a.nx;
+    const int R = a.ring[blockIdx.y];
+    const long long lo = (long long)R * R;
+    for (int i = threadIdx.x; i < a.nfine; i += blockDim.x) lhist[i] = 0.0;
+    __syncthreads();
+    const size_t n = (size_t)a.ny * a.nx;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / a.nx), j = (int)(e % a.nx);
+        double fx, fy;
+        long long r2;
+        psd_coords(i, j, a.ny, a.nx, fx, fy, r2);
+        const long long d = r2 - lo;
+        if (d < 0 || d >= a.nfine) continue;
+        if ((int)floor(sqrt((double)r2)) != R) continue;
+        const double fr = sqrt(__dadd_rn(__dmul_rn(fx, fx), __dmul_rn(fy, fy)));
+        if (!(fr <= fmax)) continue;
+        double p = (double)P[e];
+        if (i == a.ny / 2 && j == a.nx / 2) p = 0.0;
+        if (!isfinite(p)) p = 0.0;
+        if (p != 0.0) atomicAdd(&lhist[(int)d], p);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.nfine; i += blockDim.x)
+        if (lhist[i] != 0.0) atomicAdd(&a.fine[(size_t)blockIdx.y * a.nfine + i], lhist[i]);
+}
+
+// f95 = sqrt(r2*)/n of the first exact radius whose cumulative power reaches 0.95 S.  grid (batch), block 64
+__global__ void k_psd_stats_fin(PsdStatArgs a, const int* __restrict__ ring, const double* __restrict__ below,
+                                double* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const int b = blockIdx.x;
+    const double tot = out[(size_t)b * 8 + 7];
+    const long long lo = (long long)ring[b] * ring[b];
+    double cum = below[b];
+    long long r2 = lo;
+    bool found = false;
+    for (int i = 0; i < a.nfine; ++i) {
+        const double c = a.fine[(size_t)b * a.nfine + i];
+        if (c == 0.0) continue;
+        r2 = lo + i;
+        if ((cum + c) / tot >= 0.95) {
+            found = true;
+            break;
+        }
+        cum += c;
+    }
+    (void)found;
+    out[(size_t)b * 8 + 7] = sqrt((double)r2) / (double)a.nx;
+}
+
 }  // namespace b4d
 
 using namespace b4d;
@@ -366,6 +596,70 @@ int b4d_sobel_laplace_stats(const float* frames, int batch, int ny, int nx, doub
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sobel_lap, grid, dim3(64, 4), 0, st, frames, ny, nx, static_cast<double*>(ws));
     hipLaunchKernelGGL(k_sobel_fin, dim3(batch), dim3(256), 0, st, static_cast<const double*>(ws), nblk, out);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+
+int b4d_percentiles(const float* frames, int batch, size_t npix, const double* q_host, int nq, double* out,
+                    void* stream) {
+    if (!frames || !q_host || !out) return fail(B4D_EINVAL, "null argument");
+    if (batch < 1 || npix < 1 || nq < 1 || nq > 16) return fail(B4D_EINVAL, "batch, npix >= 1 and 1 <= nq <= 16 required");
+    if (npix > 0xffffffffull) return fail(B4D_EINVAL, "frame too large");
+    void* ws = nullptr;
+    int rc = get_scratch(sizeof(double) * 16, &ws);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    B4D_HIP(hipMemcpyAsync(ws, q_host, sizeof(double) * nq, hipMemcpyHostToDevice, st));
+    B4D_HIP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_percentiles, dim3(batch), dim3(1024), 0, st, frames, npix, static_cast<const double*>(ws), nq, out);
+    B4D_HIP(hipGetLastError());
+    B4D_HIP(hipStreamSynchronize(st));  // the shared scratch holds q until the kernel has run
+    return B4D_OK;
+}
+
+int b4d_radial_profile(const float* maps, int batch, int ny, int nx, int nr, int ntheta, double r_max, double* out,
+                       void* stream) {
+    if (!maps || !out) return fail(B4D_EINVAL, "null argument");
+    if (batch < 1 || ny < 2 || nx < 2 || nr < 2 || ntheta < 4 || !(r_max > 0)) return fail(B4D_EINVAL, "bad shape / sampling");
+    hipLaunchKernelGGL(k_radial_profile, dim3(nr, batch), dim3(256), 0, (hipStream_t)stream, maps, ny, nx, nr, ntheta, r_max, out);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int b4d_psd_stats(const float* psd, int batch, int ny, int nx, double* out, void* stream) {
+    if (!psd || !out) return fail(B4D_EINVAL, "null argument");
+    if (batch < 1 || ny < 2 || nx < 2) return fail(B4D_EINVAL, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const bool square = ny == nx;
+    PsdStatArgs a{};
+    a.psd = psd;
+    a.ny = ny;
+    a.nx = nx;
+    a.nblk = 256;
+    a.ncoarse = square ? nx / 2 + 2 : 0;
+    a.nfine = square ? 2 * (nx / 2 + 2) + 1 : 0;
+    const size_t nd = (size_t)batch * (8 * a.nblk + a.ncoarse + a.nfine + 2) + 64;
+    void* ws = nullptr;
+    int rc = get_scratch(sizeof(double) * nd + sizeof(int) * batch, &ws);
+    if (rc) return rc;
+    double* base = static_cast<double*>(ws);
+    a.part = base;
+    a.coarse = a.part + (size_t)batch * 8 * a.nblk;
+    a.fine = a.coarse + (size_t)batch * a.ncoarse;
+    double* below = a.fine + (size_t)batch * a.nfine;
+    int* ring = reinterpret_cast<int*>(below + batch + 2);
+    a.ring = ring;
+    B4D_HIP(hipMemsetAsync(a.coarse, 0, sizeof(double) * (size_t)batch * (a.ncoarse + a.nfine), st));
+    // f_max = min(max|fx|, max|fy|) of the shifted fftfreq axes
+    auto amax = [](int n) { return (double)(n / 2) / (double)n; };
+    const double fmax = std::fmin(amax(nx), amax(ny));
+    hipLaunchKernelGGL(k_psd_stats1, dim3(a.nblk, batch), dim3(256), sizeof(double) * a.ncoarse, st, a, fmax);
+    hipLaunchKernelGGL(k_psd_stats_mid, dim3(batch), dim3(64), 0, st, a, out, ring, below);
+    if (square) {
+        hipLaunchKernelGGL(k_psd_stats2, dim3(a.nblk, batch), dim3(256), sizeof(double) * a.nfine, st, a, fmax);
+        hipLaunchKernelGGL(k_psd_stats_fin, dim3(batch), dim3(64), 0, st, a, ring, below, out);
+    }
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }

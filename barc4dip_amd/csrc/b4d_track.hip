@@ -9,6 +9,7 @@
 // Image spectra are computed once and reused by every template (the reference re-transforms
 // the same frame 18 times per time step, metrics/speckles.py:347-415).
 #include "b4d_fft2d.hpp"
+#include "b4d_select.hpp"
 
 namespace b4d {
 
@@ -113,59 +114,6 @@ struct FinArgs {
     double eps;
 };
 
-// Exact k-th smallest (0-based) of n non-negative floats by 3-pass radix select on the bit patterns
-// (11 + 11 + 10 bits).  Whole workgroup participates; result in every thread.  Also returns the number
-// of elements strictly below and equal to the selected value.
-__device__ unsigned radix_select(const float* __restrict__ x, unsigned n, unsigned k, unsigned* hist /*[2048]*/,
-                                 unsigned* sh /*[4]*/, unsigned& n_less, unsigned& n_equal) {
-    unsigned prefix = 0, mask = 0, below = 0;
-    const int shifts[3] = {21, 10, 0};
-    const int widths[3] = {11, 11, 10};
-    for (int pass = 0; pass < 3; ++pass) {
-        const int sft = shifts[pass], nb = 1 << widths[pass];
-        for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
-            const unsigned key = __float_as_uint(x[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> sft) & (nb - 1)], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {  // one wave: 32 bins per lane, then a wave scan
-            const int per = 2048 / 64;
-            unsigned s = 0;
-            for (int i = 0; i < per; ++i) s += hist[threadIdx.x * per + i];
-            unsigned incl = s;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned t = __shfl_up(incl, o, 64);
-                if ((int)threadIdx.x >= o) incl += t;
-            }
-            const unsigned excl = incl - s, kk = k - below;
-            if (kk >= excl && kk < incl) {  // the bin is in this lane's range
-                unsigned run = excl;
-                for (int i = 0; i < per; ++i) {
-                    const unsigned c = hist[threadIdx.x * per + i];
-                    if (kk < run + c) {
-                        sh[0] = threadIdx.x * per + i;
-                        sh[1] = run;
-                        sh[2] = c;
-                        break;
-                    }
-                    run += c;
-                }
-            }
-        }
-        __syncthreads();
-        prefix |= sh[0] << sft;
-        mask |= (unsigned)(nb - 1) << sft;
-        below += sh[1];
-        n_equal = sh[2];
-        __syncthreads();
-    }
-    n_less = below;
-    return prefix;
-}
-
 // grid (pairs), block 1024
 __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
     __shared__ unsigned hist[2048];
@@ -200,27 +148,11 @@ __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
     unsigned nl, ne;
     float med;
     if (n & 1u) {
-        med = __uint_as_float(radix_select(mag, n, n / 2, hist, sh, nl, ne));
+        med = key2f(radix_select(mag, n, n / 2, hist, sh, nl, ne));
     } else {
         const unsigned ka = radix_select(mag, n, n / 2 - 1, hist, sh, nl, ne);
-        float a = __uint_as_float(ka), b = a;
-        if (nl + ne <= n / 2) {  // the upper middle value is the next larger element
-            unsigned best = 0x7f800000u;
-            for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
-                const unsigned key = __float_as_uint(mag[i]);
-                if (key > ka && key < best) best = key;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned t = __shfl_down(best, o, 64);
-                best = t < best ? t : best;
-            }
-            if ((threadIdx.x & 63) == 0) hist[threadIdx.x >> 6] = best;
-            __syncthreads();
-            best = hist[0];
-            for (int i = 1; i < 16; ++i) best = hist[i] < best ? hist[i] : best;
-            b = __uint_as_float(best);
-        }
+        float a = key2f(ka), b = a;
+        if (nl + ne <= n / 2) b = key2f(next_larger_key(mag, n, ka, hist));  // upper middle value = next larger element
         med = __fmul_rn(__fadd_rn(a, b), 0.5f);
     }
     if (threadIdx.x != 0) return;

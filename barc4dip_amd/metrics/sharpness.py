@@ -1,0 +1,264 @@
+"""Sharpness metrics on the GPU -- drop-in for ``barc4dip.metrics.sharpness`` (sharpness.py:89-861).
+
+Tenengrad and Laplacian variance use a fused 3x3 stencil + reduction kernel with scipy's "reflect" borders;
+spectral entropy and the inverse autocorrelation widths reuse the FFT pipeline; STA2 eigenvalues call the
+device SVD of torch.linalg (rocSOLVER) in float64 -- a library call kept until the Gram/eigen kernel of
+SURVEY.md §7 step 8 exists.  Tile policy as in speckles.py.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+from typing import Literal, Sequence
+
+import numpy as np
+
+from .. import _device as D
+from .. import _ffi
+from ..signal import corr as _corr
+from ..signal import fft as _fft
+from . import kernels as K
+from .common import (apply_display_origin, choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
+                     tile_spans, tiled_scalar_fields, tiles_meta)
+from .speckles import _dev2d, _fft_ok, _pad4, _pad_square_dev, _tile_batches, _widths_from_autocorr
+from .statistics import distribution_moments, moments_from_sums
+
+logger = logging.getLogger(__name__)
+
+_SHARPNESS_UNITS: dict[str, dict[str, str]] = {
+    "stats": {"mean": "a.u.", "std": "a.u.", "variance": "a.u.^2", "skewness": "", "kurtosis": "", "frac_zero": "",
+              "frac_sat": "", "SNRdB": "dB"},
+    "gradient": {"tenengrad": "a.u.^2", "ex": "a.u.^2", "ey": "a.u.^2", "re": ""},
+    "laplacian": {"laplacian_variance": "a.u.^2"},
+    "spectral": {"spectral_entropy": ""},
+    "autocorrelation": {"sx": "1/px", "sy": "1/px", "seq": "1/px", "r": ""},
+    "eigenvalues": {"eigenvalues": "", "e1": "", "e2": "", "re": ""},
+}
+_ALL_SHARPNESS_GROUPS: set[str] = {"stats", "gradient", "laplacian", "spectral", "autocorrelation", "eigenvalues"}
+_FFT_GROUPS = {"spectral", "autocorrelation"}
+
+
+def _check2d(image, who: str, all_finite: bool = False):
+    data = image if D.is_tensor(image) else np.asarray(image)
+    if data.ndim != 2:
+        raise ValueError(f"Expected 2D array, got ndim={data.ndim}")
+    if int(np.prod(tuple(data.shape))) == 0:
+        raise ValueError(f"{who} received an empty image.")
+    t = _dev2d(data)
+    fin = t.isfinite()
+    if all_finite:
+        if not bool(fin.all()):
+            raise ValueError(f"{who} requires all values to be finite.")
+    elif not bool(fin.any()):
+        raise ValueError(f"{who} received image with no finite values.")
+    return t
+
+
+def _gradient_from(row, eps: float) -> dict:
+    ex, ey = float(row[0]), float(row[1])
+    return {"tenengrad": float(ex + ey), "ex": ex, "ey": ey, "re": float(ex / (ey + float(eps)))}
+
+
+def tenengrad(image, *, eps: float = 1e-12, verbose: bool = False) -> dict:
+    """mean(gx^2) + mean(gy^2) of the Sobel gradients over finite pixels (reference: sharpness.py:405-476)."""
+    t = _check2d(image, "tenengrad")
+    out = _gradient_from(K.sobel_laplace_batch(t[None]).cpu().numpy()[0], eps)
+    if verbose:
+        logger.info("> tenengrad: %.6g | ex: %.6g | ey: %.6g | ex/ey: %.3f", out["tenengrad"], out["ex"], out["ey"], out["re"])
+    return out
+
+
+def laplacian_variance(image, *, verbose: bool = False) -> float:
+    """Population variance of the 5-point Laplacian over finite pixels (reference: sharpness.py:482-530)."""
+    t = _check2d(image, "laplacian_variance")
+    row = K.sobel_laplace_batch(t[None]).cpu().numpy()[0]
+    var = float(row[3] - row[2] * row[2])
+    if verbose:
+        logger.info("> laplacian variance: %.6g", var)
+    return var
+
+
+def _entropy_from(row, size: int, remove_dc: bool) -> float:
+    s_all, splnp = float(row[5]), float(row[6])
+    if not np.isfinite(s_all) or s_all <= 0.0:
+        raise ValueError("PSD sum is non-positive; cannot compute spectral entropy.")
+    m = int(size - 1) if remove_dc else int(size)
+    if m < 2:
+        raise ValueError("Insufficient number of spectral bins to compute normalized entropy.")
+    h = np.log(s_all) - splnp / s_all          # -sum p ln p with p = P / S
+    return float(h / np.log(float(m)))
+
+
+def spectral_entropy(image, *, remove_mean: bool = True, remove_dc: bool = True, eps: float = 1e-30,
+                     verbose: bool = False) -> float:
+    """Normalised Shannon entropy of the PSD (reference: sharpness.py:536-629; like the reference, the image is
+    NOT padded to a square).  The eps clip of the reference changes the value by < 1e-27 and is not applied."""
+    t = _check2d(image, "spectral_entropy", all_finite=True)
+    if not (remove_mean and remove_dc):
+        raise NotImplementedError("the GPU path implements the default remove_mean=True, remove_dc=True")
+    psd = _fft.psd2d_stack(t[None], scale=False, return_tensors=True)
+    hn = _entropy_from(K.psd_stats_batch(psd)[0], int(t.numel()), remove_dc)
+    if verbose:
+        logger.info("> spectral_entropy: %.6g", hn)
+    return hn
+
+
+def inverse_autocorr_width(image, *, fraction: float = 1.0 / np.e,
+                           radial_method: Literal["binned", "interpolated"] = "interpolated", min_size_px: int = 32,
+                           verbose: bool = False) -> dict:
+    """sx = 1/lx, sy = 1/ly, seq = 1/leq, r = lx/ly from the standardised autocorrelation
+    (reference: sharpness.py:635-746; "binned" also uses the interpolated estimator there, 704-707)."""
+    data = image if D.is_tensor(image) else np.asarray(image)
+    if data.ndim != 2:
+        raise ValueError("image must be a 2D array.")
+    if int(np.prod(tuple(data.shape))) == 0:
+        raise ValueError("inverse_autocorr_width received an empty image.")
+    if min(data.shape) < int(min_size_px):
+        raise ValueError(f"image too small for inverse autocorrelation width (min dimension < {int(min_size_px)}).")
+    if radial_method not in ("binned", "interpolated"):
+        raise ValueError("radial_method must be 'binned' or 'interpolated'.")
+    sq = _pad_square_dev(_dev2d(data))
+    ac, _, _ = _corr.autocorr2d(sq, dx=1.0, dy=1.0, remove_mean=True, standardize=True, normalize="peak", return_tensors=True)
+    lx, ly, leq = _widths_from_autocorr(ac, fraction, "interpolated")
+    inv = lambda v: float(1.0 / v) if v != 0.0 else float("inf")  # noqa: E731
+    out = {"sx": inv(lx), "sy": inv(ly), "seq": inv(float(leq)), "r": float(lx / ly) if ly != 0.0 else float("inf")}
+    if verbose:
+        logger.info("> inv_ac_width: sx=%.4g | sy=%.4g | seq=%.4g | r(lx/ly)=%.3g", out["sx"], out["sy"], out["seq"], out["r"])
+    return out
+
+
+def eigenvalues(image, *, k: int = 5, eps: float = 1e-30, verbose: bool = False) -> dict:
+    """STA2: eig = s^2/(M*N-1) of the energy-normalised, mean-removed image; sum of the first k, e1, e2, e1/e2
+    (reference: sharpness.py:752-861)."""
+    import torch
+
+    t = _check2d(image, "eigenvalues", all_finite=True)
+    if int(k) < 1:
+        raise ValueError("k must be >= 1.")
+    x = t.double()
+    energy = float(torch.sqrt((x * x).sum()))
+    if not np.isfinite(energy) or energy <= 0.0:
+        raise ValueError("eigenvalues cannot normalize an all-zero image.")
+    j = x / energy
+    j = j - j.mean()
+    denom = float(j.numel() - 1)
+    if denom <= 0.0:
+        raise ValueError("eigenvalues requires at least 2 pixels (M*N >= 2).")
+    s = torch.linalg.svdvals(j)
+    eig = ((s * s) / denom).cpu().numpy()
+    e1 = float(eig[0]) if eig.size >= 1 else 0.0
+    e2 = float(eig[1]) if eig.size >= 2 else 0.0
+    out = {"eigenvalues": float(np.sum(eig[:min(int(k), int(eig.size))])), "e1": e1, "e2": e2, "re": float(e1 / (e2 + float(eps)))}
+    if verbose:
+        logger.info("> eigenvalues: %.6g | e1: %.6g | e2: %.6g | e1/e2: %.3f", out["eigenvalues"], e1, e2, out["re"])
+    return out
+
+
+def _tiles_pointwise(t, tile_mode, groups, saturation_value, eps):
+    n, batches = _tile_batches(t, tile_mode)
+    st = grad = lap = None
+    for _, rcs, stack in batches:
+        mom = K.moments_batch(_pad4(stack), eps=eps, saturation=saturation_value).cpu().numpy() if "stats" in groups else None
+        sl = K.sobel_laplace_batch(stack).cpu().numpy() if groups & {"gradient", "laplacian"} else None
+        for i, (r, c) in enumerate(rcs):
+            if mom is not None:
+                d = moments_from_sums(mom[i], saturation_value)
+                st = st or {k: np.empty((n, n)) for k in d}
+                for k in st:
+                    st[k][r, c] = d[k]
+            if "gradient" in groups:
+                g = _gradient_from(sl[i], 1e-12)
+                grad = grad or {k: np.empty((n, n)) for k in g}
+                for k in grad:
+                    grad[k][r, c] = g[k]
+            if "laplacian" in groups:
+                lap = lap if lap is not None else {"laplacian_variance": np.empty((n, n))}
+                lap["laplacian_variance"][r, c] = float(sl[i][3] - sl[i][2] * sl[i][2])
+    out = {}
+    if st is not None:
+        out["stats"] = grids_to_fields(st, n)
+    if grad is not None:
+        out["gradient"] = grids_to_fields(grad, n)
+    if lap is not None:
+        out["laplacian"] = grids_to_fields(lap, n)
+    return out
+
+
+def sharpness_stats(image: np.ndarray, *, metrics: str | Sequence[str] = "all", tiles: bool = True,
+                    display_origin: Literal["upper", "lower"] = "lower", saturation_value: float | None = 65535.0,
+                    eps: float = 1e-6, verbose: bool = True) -> dict:
+    """Sharpness metrics of one 2-D image: {"meta", "full", "tiles"} (reference: sharpness.py:89-288)."""
+    if not isinstance(image, np.ndarray):
+        raise TypeError("sharpness_stats expects a numpy.ndarray")
+    if image.ndim != 2:
+        raise ValueError(f"Expected 2D array, got ndim={image.ndim}")
+    image = apply_display_origin(image, display_origin=display_origin)
+    h, w = image.shape
+    groups = normalize_groups(metrics, all_groups=_ALL_SHARPNESS_GROUPS, context="sharpness", param_name="metrics")
+    if verbose:
+        logger.info("\nsharpness stats for a (h x w: %.0f x %.0f) image:", h, w)
+    out: dict = {"meta": {"kind": "sharpness", "display_origin": display_origin, "input_shape": (int(h), int(w)),
+                          "requested_groups": sorted(groups), "units": _SHARPNESS_UNITS}, "full": {}}
+    t = _dev2d(np.ascontiguousarray(image))
+    if "stats" in groups:
+        out["full"]["stats"] = distribution_moments(t, saturation_value=saturation_value, eps=eps, verbose=verbose)
+    if "gradient" in groups:
+        out["full"]["gradient"] = tenengrad(t, verbose=verbose)
+    if "laplacian" in groups:
+        out["full"]["laplacian"] = {"laplacian_variance": laplacian_variance(t, verbose=verbose)}
+    if "spectral" in groups:
+        out["full"]["spectral"] = {"spectral_entropy": spectral_entropy(t, verbose=verbose)}
+    if "autocorrelation" in groups:
+        out["full"]["autocorrelation"] = inverse_autocorr_width(t, verbose=verbose)
+    if "eigenvalues" in groups:
+        out["full"]["eigenvalues"] = eigenvalues(t, verbose=verbose)
+
+    mode, tile_shape_px = choose_tiling_mode(h, w, tiles=tiles, min_tile_px=128)
+    if mode == "off":
+        return out
+    out["meta"].update(tiles_meta(h, w, tile_mode=mode, tile_shape_px=tile_shape_px))
+    tiles_out = _tiles_pointwise(t, mode, groups, saturation_value, eps)
+    if "eigenvalues" in groups:
+        tiles_out["eigenvalues"] = tiled_scalar_fields(t, tile_mode=mode, compute_fn=eigenvalues)
+    fft_groups = sorted(groups & _FFT_GROUPS)
+    if fft_groups:
+        n, ys, xs = tile_spans(h, w, mode)
+        if all(_fft_ok((y1 - y0, x1 - x0)) and (y1 - y0) == (x1 - x0) for y0, y1 in ys for x0, x1 in xs):
+            if "spectral" in groups:
+                tiles_out["spectral"] = tiled_scalar_fields(t, tile_mode=mode, compute_fn=lambda v: {"spectral_entropy": spectral_entropy(v)})
+            if "autocorrelation" in groups:
+                tiles_out["autocorrelation"] = tiled_scalar_fields(t, tile_mode=mode, compute_fn=inverse_autocorr_width)
+        else:
+            warnings.warn(f"tile statistics of {fft_groups} skipped: {tile_shape_px}-pixel tiles need a general-length "
+                          "FFT plan (not built yet); full-frame values are unaffected.", RuntimeWarning, stacklevel=2)
+    if tiles_out:
+        order = ("stats", "gradient", "laplacian", "spectral", "autocorrelation", "eigenvalues")
+        out["tiles"] = {g: tiles_out[g] for g in order if g in tiles_out}
+    return out
+
+
+def sharpness_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "all", tiles: bool = True,
+                          display_origin: Literal["upper", "lower"] = "lower", saturation_value: float | None = 65535.0,
+                          eps: float = 1e-6, verbose: bool = True, parallel: bool = True, n_jobs: int | None = None) -> dict:
+    """Per-frame sharpness metrics stacked along T (reference: sharpness.py:290-399)."""
+    if not isinstance(stack, np.ndarray):
+        raise TypeError("sharpness_stack_stats expects a numpy.ndarray")
+    if stack.ndim != 3:
+        raise ValueError(f"stack must be a 3D array with shape (T, H, W); got ndim={stack.ndim}")
+    T, H, W = (int(v) for v in stack.shape)
+    if T < 1:
+        raise ValueError("stack must contain at least one frame.")
+    groups = normalize_groups(metrics, all_groups=_ALL_SHARPNESS_GROUPS, context="sharpness", param_name="metrics")
+    tile_mode, tile_shape_px = choose_tiling_mode(H, W, tiles=tiles)
+    per_frame = [sharpness_stats(stack[t], metrics=metrics, tiles=tiles, display_origin=display_origin,
+                                 saturation_value=saturation_value, eps=eps, verbose=False) for t in range(T)]
+    meta = {"kind": "sharpness_stack_stats", "input_shape": (H, W), "stack_shape": (T, H, W), "n_frames": T,
+            "display_origin": display_origin, "requested_groups": sorted(groups), "units": _SHARPNESS_UNITS,
+            "parallel": {"enabled": False, "n_jobs": None}}
+    meta.update(tiles_meta(H, W, tile_mode=tile_mode, tile_shape_px=tile_shape_px))
+    out = {"meta": meta, "full": stack_time_series([d["full"] for d in per_frame])}
+    if tiles and all(isinstance(d.get("tiles"), dict) for d in per_frame):
+        out["tiles"] = stack_time_series([d["tiles"] for d in per_frame])
+    if verbose:
+        logger.info("> sharpness_stack_stats | frames=%d | device batch", T)
+    return out

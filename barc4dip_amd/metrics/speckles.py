@@ -1,0 +1,360 @@
+"""Speckle-field metrics on the GPU -- drop-in for ``barc4dip.metrics.speckles``.
+
+Same functions, keyword arguments, dict schemas and exceptions as the reference (speckles.py:83-817).  The
+array work runs in libb4d: autocorrelation / PSD (one forward transform each), moments, percentile selection,
+polar radial profile, PSD disc statistics, phase-correlation tracking; only the 1-D crossing searches on a few
+thousand samples stay on the host.  Differences: device arithmetic is float32; FFT-based
+groups need power-of-two frame sizes, so FFT-based TILE statistics (170/171- or 227/228-pixel tiles) are
+skipped with a RuntimeWarning until general-length plans exist; the default tracker of the reference
+(`tracking_method="template"`, scikit-image) is unavailable like in the reference without that library --
+use ``tracking_method="phase", tracking_backend="internal"``.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+from typing import Literal, Sequence
+
+import numpy as np
+
+from .. import _device as D
+from .. import _ffi
+from ..geometry.roi import odd_size, roi_grid_3x3
+from ..maths.radial import radial_mean_binned, radial_profile_batch
+from ..maths.stats import distance_at_fraction_from_peak, width_at_fraction
+from ..signal import corr as _corr
+from ..signal import fft as _fft
+from ..signal.tracking import phase_correlation_batch
+from . import kernels as K
+from .common import (apply_display_origin, choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
+                     tile_spans, tiles_meta)
+from .statistics import moments_from_sums
+
+logger = logging.getLogger(__name__)
+
+_SPECKLE_UNITS: dict[str, dict[str, str]] = {
+    "amplitude": {"visibility": "", "contrast": ""},
+    "stats": {"mean": "a.u.", "std": "a.u.", "variance": "a.u.^2", "skewness": "", "kurtosis": "", "frac_zero": "",
+              "frac_sat": "", "SNRdB": "dB"},
+    "grain": {"lx": "px", "ly": "px", "leq": "px", "r": "", "xlag": "px", "ylag": "px", "autocorr": ""},
+    "bandwidth": {"spr": "", "feq": "1/px", "f95": "1/px", "sig_fx": "1/px", "sig_fy": "1/px", "rf": ""},
+    "temporal": {"dx": "px", "dy": "px", "r": "px", "std_dx": "px", "std_dy": "px", "std_r": "px"},
+}
+_ALL_SPECKLE_GROUPS: set[str] = {"amplitude", "grain", "bandwidth", "stats"}
+_FFT_GROUPS = {"grain", "bandwidth"}
+
+
+# ------------------------------------------------------------------------------------------------ device helpers
+def _dev2d(image):
+    t, _, _ = D.to_device_f32(image, ndim=(2,))
+    return t
+
+
+def _pad_square_dev(t):
+    """pad_to_square(fill = mean) on the device (geometry/masks.py:11-57)."""
+    import torch
+
+    h, w = t.shape
+    if h == w:
+        return t
+    n = max(h, w)
+    out = torch.full((n, n), float(t.double().mean()), dtype=torch.float32, device=t.device)
+    y0, x0 = (n - h) // 2, (n - w) // 2
+    out[y0:y0 + h, x0:x0 + w] = t
+    return out
+
+
+def _fft_ok(shape) -> bool:
+    n = max(shape)
+    return _ffi.supported(n, n)
+
+
+def _amplitude_from(mom_row, pct_row) -> dict:
+    n, mean, m2 = float(mom_row[0]), float(mom_row[1]), float(mom_row[2])
+    if not np.isfinite(mean) or mean <= 0.0 or n <= 0:
+        raise ValueError("Mean intensity must be positive and finite.")
+    vmin, vmax = float(pct_row[0]), float(pct_row[1])
+    denom = vmax + vmin
+    if not np.isfinite(denom) or denom <= 0.0:
+        raise ValueError("Invalid percentile range for Michelson contrast.")
+    return {"visibility": float(np.sqrt(m2 / n)) / mean, "contrast": (vmax - vmin) / denom}
+
+
+def _widths_from_autocorr(ac_dev, fraction: float, radial_method: str):
+    """lx, ly (1/e full widths of the cuts through the peak) and leq (from the radial mean) of ONE device map."""
+    n_y, n_x = (int(v) for v in ac_dev.shape)
+    flat = int(ac_dev.argmax())
+    iy, ix = divmod(flat, n_x)
+    y_cut = ac_dev[:, ix].double().cpu().numpy()
+    x_cut = ac_dev[iy, :].double().cpu().numpy()
+    ly, _ = width_at_fraction(y_cut, fraction=fraction, center_index=iy)
+    lx, _ = width_at_fraction(x_cut, fraction=fraction, center_index=ix)
+    if radial_method == "binned":
+        rad, r = radial_mean_binned(ac_dev)
+    else:
+        rad2, r = radial_profile_batch(ac_dev[None])
+        rad = rad2[0]
+    if rad.size < 2 or r.size < 2:
+        raise ValueError("Radial profile is too short to estimate leq.")
+    dr = float(r[1] - r[0])
+    if dr <= 0:
+        raise ValueError("Invalid radial sampling (non-positive dr).")
+    dist, _ = distance_at_fraction_from_peak(rad, fraction=fraction, peak_index=0)
+    return float(lx), float(ly), 2 * float(dist) * dr
+
+
+def _bandwidth_from(stats_row) -> dict:
+    s, sfr, sfx, sfy, sp2, _, _, f95 = (float(v) for v in stats_row)
+    if not np.isfinite(s) or s <= 0.0:
+        raise ValueError("PSD energy is not positive/finite after mean/DC removal.")
+    sig_fx, sig_fy = float(np.sqrt(sfx / s)), float(np.sqrt(sfy / s))
+    den = sp2 / (s * s)
+    if not np.isfinite(den) or den <= 0.0:
+        raise ValueError("Invalid SPR denominator (unexpected).")
+    return {"feq": float(np.sqrt(sfr / s)), "f95": f95, "sig_fx": sig_fx, "sig_fy": sig_fy,
+            "rf": float(sig_fx / sig_fy) if sig_fy != 0.0 else float("inf"), "spr": float(1.0 / den)}
+
+
+# ------------------------------------------------------------------------------------------------ metric functions
+def grain(image, *, fraction: float = 1.0 / np.e, radial_method: Literal["binned", "interpolated"] = "interpolated",
+          verbose: bool = False) -> dict:
+    """Speckle grain size from the autocorrelation peak: lx, ly, leq, r = lx/ly, autocorr, xlag, ylag
+    (reference: speckles.py:497-596)."""
+    data = image if D.is_tensor(image) else np.asarray(image)
+    if data.ndim != 2:
+        raise ValueError("image must be a 2D array.")
+    if min(data.shape) < 128:
+        raise ValueError("image too small for speckle grain metrics (min dimension < 128).")
+    if radial_method not in ("binned", "interpolated"):
+        raise ValueError("radial_method must be 'binned' or 'interpolated'.")
+    sq = _pad_square_dev(_dev2d(data))
+    ac, xlag, ylag = _corr.autocorr2d(sq, dx=1.0, dy=1.0, remove_mean=True, standardize=False, normalize="peak",
+                                      return_tensors=True)
+    lx, ly, leq = _widths_from_autocorr(ac, fraction, radial_method)
+    out = {"lx": lx, "ly": ly, "leq": float(leq), "r": float(lx / ly) if ly != 0 else float("inf"),
+           "autocorr": D.to_host(ac, np.float64), "xlag": np.asarray(xlag, dtype=float), "ylag": np.asarray(ylag, dtype=float)}
+    if verbose:
+        logger.info("> grain: lx=%.2f | ly=%.2f | lx/ly=%.2f | leq=%.2f ", out["lx"], out["ly"], out["r"], out["leq"])
+    return out
+
+
+def amplitude(image, verbose: bool = False) -> dict:
+    """visibility = std/mean and robust Michelson contrast from the 0.05 / 99.95 percentiles
+    (reference: speckles.py:602-663)."""
+    data = image if D.is_tensor(image) else np.asarray(image)
+    if data.ndim != 2:
+        raise ValueError("image must be a 2D array.")
+    t = _dev2d(data)[None]
+    mom = K.moments_batch(_pad4(t), eps=0.0, saturation=None).cpu().numpy()[0]
+    pct = K.percentiles_batch(t, [0.05, 99.95])[0]
+    out = _amplitude_from(mom, pct)
+    if verbose:
+        logger.info("> visibility: %.2f | contrast: %.2f", out["visibility"], out["contrast"])
+    return out
+
+
+def _pad4(t):
+    """(B, ...) -> (B, npix padded to a multiple of 4 with NaN) for the 16-byte-vector moment kernel."""
+    import torch
+
+    flat = t.reshape(t.shape[0], -1)
+    pad = (-flat.shape[1]) % 4
+    if pad:
+        flat = torch.cat([flat, torch.full((flat.shape[0], pad), float("nan"), device=flat.device)], dim=1)
+    return flat
+
+
+def bandwidth(image, verbose: bool = False) -> dict[str, float]:
+    """Spatial-frequency bandwidth metrics of the PSD over the inscribed frequency disc: feq, f95, sig_fx, sig_fy,
+    rf, spr (reference: speckles.py:669-817)."""
+    data = image if D.is_tensor(image) else np.asarray(image)
+    if data.ndim != 2:
+        raise ValueError("image must be a 2D array.")
+    sq = _pad_square_dev(_dev2d(data))
+    if not bool(sq.isfinite().all()):
+        raise ValueError("image mean is not finite.")
+    psd = _fft.psd2d_stack(sq[None], scale=True, return_tensors=True)   # mean removal == zeroed DC bin (kernel)
+    out = _bandwidth_from(K.psd_stats_batch(psd)[0])
+    if verbose:
+        logger.info("> bandwidth: fx=%.4f | fy=%.4f | fx/fy=%.2f | feq=%.4f | f95=%.4f | spr=%.0f", out["sig_fx"],
+                    out["sig_fy"], out["rf"], out["feq"], out["f95"], out["spr"])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ tiles
+def _tile_batches(t, tile_mode: str):
+    """Tiles of a device image grouped by shape -> (n, [(shape, rc_list, stacked (k, th, tw) tensor)])."""
+    import torch
+
+    n, ys, xs = tile_spans(int(t.shape[0]), int(t.shape[1]), tile_mode)
+    groups: dict[tuple[int, int], list] = {}
+    for r, (y0, y1) in enumerate(ys):
+        for c, (x0, x1) in enumerate(xs):
+            groups.setdefault((y1 - y0, x1 - x0), []).append((r, c, t[y0:y1, x0:x1]))
+    out = []
+    for shape, items in groups.items():
+        out.append((shape, [(r, c) for r, c, _ in items], torch.stack([v for _, _, v in items]).contiguous()))
+    return n, out
+
+
+def _tiles_pointwise(t, tile_mode: str, want_amp: bool, want_stats: bool, saturation_value, eps):
+    """amplitude / stats tile grids from batched kernels over all tiles."""
+    n, batches = _tile_batches(t, tile_mode)
+    amp = {k: np.empty((n, n)) for k in ("visibility", "contrast")} if want_amp else None
+    st = None
+    for _, rcs, stack in batches:
+        mom = K.moments_batch(_pad4(stack), eps=eps, saturation=saturation_value).cpu().numpy()
+        pct = K.percentiles_batch(stack, [0.05, 99.95]) if want_amp else None
+        for i, (r, c) in enumerate(rcs):
+            if want_amp:
+                a = _amplitude_from(mom[i], pct[i])
+                for k in amp:
+                    amp[k][r, c] = a[k]
+            if want_stats:
+                d = moments_from_sums(mom[i], saturation_value)
+                if st is None:
+                    st = {k: np.empty((n, n)) for k in d}
+                for k in st:
+                    st[k][r, c] = d[k]
+    out = {}
+    if want_amp:
+        out["amplitude"] = grids_to_fields(amp, n)
+    if want_stats:
+        out["stats"] = grids_to_fields(st, n)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ aggregators
+def speckle_stats(image: np.ndarray, *, metrics: str | Sequence[str] = "all", tiles: bool = True,
+                  display_origin: Literal["upper", "lower"] = "lower", saturation_value: float | None = 65535.0,
+                  eps: float = 1e-6, verbose: bool = True) -> dict:
+    """Speckle metrics of one 2-D image: {"meta", "full", "tiles"} (reference: speckles.py:83-255)."""
+    if not isinstance(image, np.ndarray):
+        raise TypeError("speckle_stats expects a numpy.ndarray")
+    if image.ndim != 2:
+        raise ValueError(f"Expected 2D array, got ndim={image.ndim}")
+    image = apply_display_origin(image, display_origin=display_origin)
+    h, w = image.shape
+    groups = normalize_groups(metrics, all_groups=_ALL_SPECKLE_GROUPS, context="speckles", param_name="metrics")
+    if verbose:
+        logger.info("\nspeckle stats for a (h x w: %.0f x %.0f) image:", h, w)
+    out: dict = {"meta": {"kind": "speckles", "display_origin": display_origin, "input_shape": (int(h), int(w)),
+                          "requested_groups": sorted(groups), "units": _SPECKLE_UNITS}, "full": {}}
+    t = _dev2d(np.ascontiguousarray(image))
+    if "amplitude" in groups:
+        out["full"]["amplitude"] = amplitude(t, verbose=verbose)
+    if "grain" in groups:
+        out["full"]["grain"] = grain(t, verbose=verbose)
+    if "stats" in groups:
+        from .statistics import distribution_moments
+
+        out["full"]["stats"] = distribution_moments(t, saturation_value=saturation_value, eps=eps, verbose=verbose)
+    if "bandwidth" in groups:
+        out["full"]["bandwidth"] = bandwidth(t, verbose=verbose)
+
+    mode, tile_shape_px = choose_tiling_mode(h, w, tiles=tiles, min_tile_px=128)
+    if mode == "off":
+        return out
+    out["meta"].update(tiles_meta(h, w, tile_mode=mode, tile_shape_px=tile_shape_px))
+    tiles_out = _tiles_pointwise(t, mode, "amplitude" in groups, "stats" in groups, saturation_value, eps)
+    fft_groups = sorted(groups & _FFT_GROUPS)
+    if fft_groups:
+        n, ys, xs = tile_spans(h, w, mode)
+        native = all(_fft_ok((y1 - y0, x1 - x0)) for y0, y1 in ys for x0, x1 in xs)
+        if native:
+            from .common import tiled_scalar_fields
+
+            if "grain" in groups:
+                tiles_out["grain"] = tiled_scalar_fields(
+                    t, tile_mode=mode, compute_fn=lambda v: {k: float(x) for k, x in grain(v).items() if k in ("lx", "ly", "leq", "r")})
+            if "bandwidth" in groups:
+                tiles_out["bandwidth"] = tiled_scalar_fields(t, tile_mode=mode, compute_fn=bandwidth)
+        else:
+            warnings.warn(f"tile statistics of {fft_groups} skipped: {tile_shape_px}-pixel tiles need a general-length "
+                          "FFT plan (not built yet); full-frame values are unaffected.", RuntimeWarning, stacklevel=2)
+    if tiles_out:
+        out["tiles"] = {g: tiles_out[g] for g in ("amplitude", "grain", "stats", "bandwidth") if g in tiles_out}
+    return out
+
+
+def speckle_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "all", tiles: bool = True,
+                        display_origin: Literal["upper", "lower"] = "lower", roi_grain_factor: float = 3.0,
+                        roi_step_factor: float = 0.5, tracking_method: str = "template",
+                        tracking_backend: Literal["internal", "skimage", "opencv"] = "skimage", subpixel: bool = True,
+                        saturation_value: float | None = 65535.0, eps: float = 1e-6, verbose: bool = True,
+                        parallel: bool = True, n_jobs: int | None = None) -> dict:
+    """Per-frame speckle metrics stacked along T plus abs / inc translation tracking on a central 3x3 ROI grid
+    (reference: speckles.py:258-490).  `parallel` / `n_jobs` are accepted for signature compatibility; frames
+    are batched on the device instead of joblib threads."""
+    if not isinstance(stack, np.ndarray):
+        raise TypeError("speckle_stack_stats expects a numpy.ndarray")
+    if stack.ndim != 3:
+        raise ValueError(f"stack must be a 3D array with shape (T, H, W); got ndim={stack.ndim}")
+    T, H, W = (int(v) for v in stack.shape)
+    if T < 1:
+        raise ValueError("stack must contain at least one frame.")
+    method = tracking_method.strip().lower()
+    if method == "template":
+        if tracking_backend not in ("opencv", "skimage"):
+            raise ValueError("backend must be 'opencv' or 'skimage'.")
+        raise ImportError(f"backend={tracking_backend!r} requires "
+                          f"{'opencv-python (cv2)' if tracking_backend == 'opencv' else 'scikit-image'}; "
+                          "use tracking_method='phase', tracking_backend='internal' for the GPU tracker.")
+    if method != "phase":
+        raise ValueError(f"Unsupported tracking method: {tracking_method!r}. Supported: phase, template")
+    if tracking_backend == "skimage":
+        raise ImportError("backend='skimage' requires scikit-image.")
+    if tracking_backend != "internal":
+        raise ValueError("backend must be 'internal' or 'skimage'.")
+
+    per_frame = [speckle_stats(stack[t], metrics=metrics, tiles=tiles, display_origin=display_origin,
+                               saturation_value=saturation_value, eps=eps, verbose=False) for t in range(T)]
+    out_full = stack_time_series([d["full"] for d in per_frame])
+    out_tiles = None
+    if tiles and all(isinstance(d.get("tiles"), dict) for d in per_frame):
+        out_tiles = stack_time_series([d["tiles"] for d in per_frame])
+
+    grain0 = grain(stack[0], verbose=False)
+    ell = float(np.nanmax([grain0.get("lx", np.nan), grain0.get("ly", np.nan), grain0.get("leq", np.nan)]))
+    if not np.isfinite(ell) or ell <= 0:
+        raise ValueError("Could not infer a valid grain size from frame 0 (lx/ly/leq).")
+    roi_side = odd_size(int(np.ceil(roi_grain_factor * ell)))
+    step = int(max(1, round(roi_step_factor * roi_side)))
+    grid_slices, grid_labels = roi_grid_3x3((H, W), (roi_side, roi_side), (step, step), center_yx=None)
+    rois = [(s[0].start, s[0].stop, s[1].start, s[1].stop) for s in grid_slices.ravel()]
+
+    # abs: frame-0 templates (9, shared by every t); inc: templates cut from frame t-1 (frame 0 for t = 0)
+    tpl_frame = [0] * 9 + [max(t - 1, 0) for t in range(T) for _ in range(9)]
+    tpl_roi = rois + rois * T
+    pair_img = [t for t in range(T) for _ in range(9)] * 2
+    pair_tpl = [k for _ in range(T) for k in range(9)] + [9 + 9 * t + k for t in range(T) for k in range(9)]
+    dev, _, _ = D.to_device_f32(stack, ndim=(3,))
+    res = phase_correlation_batch(dev, dev, tpl_frame, tpl_roi, pair_img, pair_tpl, subpixel=subpixel, eps=1e-9)
+    dy_abs = res[:9 * T, 0].reshape(T, 3, 3).astype(np.float32)
+    dx_abs = res[:9 * T, 1].reshape(T, 3, 3).astype(np.float32)
+    dy_inc = res[9 * T:, 0].reshape(T, 3, 3).astype(np.float32)
+    dx_inc = res[9 * T:, 1].reshape(T, 3, 3).astype(np.float32)
+
+    def block(dx, dy):
+        r = np.sqrt(dx ** 2 + dy ** 2)
+        red = lambda fn, a: fn(a, axis=(1, 2)).astype(np.float32)  # noqa: E731
+        return {"dx": red(np.nanmean, dx), "dy": red(np.nanmean, dy), "r": red(np.nanmean, r),
+                "std_dx": red(np.nanstd, dx), "std_dy": red(np.nanstd, dy), "std_r": red(np.nanstd, r)}
+
+    meta = {"kind": "speckle_stack_stats", "input_shape": (H, W), "stack_shape": (T, H, W), "n_frames": T,
+            "display_origin": display_origin, "units": _SPECKLE_UNITS,
+            "grain0": {k: grain0.get(k) for k in ("lx", "ly", "leq", "r")},
+            "tracking": {"method": str(tracking_method), "backend": str(tracking_backend), "subpixel": bool(subpixel),
+                         "peak_mode": "abs", "search_area": "full_frame",
+                         "normalization": {"template": "zscore_local", "search": "zscore_global"},
+                         "roi_grain_factor": float(roi_grain_factor), "roi_size_yx": (int(roi_side), int(roi_side)),
+                         "roi_step_factor": float(roi_step_factor), "roi_step_yx": (int(step), int(step)),
+                         "roi_labels": grid_labels, "roi_order": "row-major"},
+            "parallel": {"enabled": False, "joblib_verbose": 0}}
+    out = {"meta": meta, "full": out_full,
+           "temporal": {"abs": block(dx_abs, dy_abs), "inc": block(dx_inc, dy_inc), "qc": {"roi_grid_shape": (3, 3)}}}
+    if out_tiles is not None:
+        out["tiles"] = out_tiles
+    if verbose:
+        logger.info("> speckle_stack_stats | frames=%d | roi=%dx%d | step=%d | device batch", T, roi_side, roi_side, step)
+    return out

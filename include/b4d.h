@@ -119,6 +119,22 @@ int b4d_moments(const float* frames, int batch, size_t npix, double eps, double 
  * out: (batch, 4) float64 {mean(gx^2), mean(gy^2), mean(lap), mean(lap^2)} over finite pixels. */
 int b4d_sobel_laplace_stats(const float* frames, int batch, int ny, int nx, double* out, void* stream);
 
+/* utils/range.py:44-54 percentile_minmax_range / np.nanpercentile (linear interpolation): exact selection
+ * of the two bracketing order statistics of the non-NaN pixels of every frame.  q: HOST array of nq (<= 16)
+ * percentiles in [0, 100].  out: DEVICE (batch, nq, 4) float64 {x_lo, x_hi, fraction, n_valid}; the caller
+ * finishes x_lo + (x_hi - x_lo) * fraction in float64.  Synchronises the stream.                          */
+int b4d_percentiles(const float* frames, int batch, size_t npix, const double* q, int nq, double* out, void* stream);
+
+/* maths/radial.py:101-169 radial_mean_interpolated: nr x ntheta polar samples, bilinear interpolation on the
+ * pixel-centre grid, zero outside, mean over theta.  out: DEVICE (batch, nr) float64.                      */
+int b4d_radial_profile(const float* maps, int batch, int ny, int nx, int nr, int ntheta, double r_max, double* out,
+                       void* stream);
+
+/* metrics/speckles.py:669-817 bandwidth + metrics/sharpness.py:536-629 spectral_entropy from a shifted PSD
+ * map (DC bin treated as zero).  out: DEVICE (batch, 8) float64 {S_disc, sum FR^2 P, sum FX^2 P, sum FY^2 P,
+ * sum P^2 (all four over the inscribed frequency disc), S_all, sum P ln P (all bins), f95 (square maps)}.  */
+int b4d_psd_stats(const float* psd, int batch, int ny, int nx, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,163 @@
+"""GPU tier: barc4dip_amd.metrics vs the vectors captured from the reference (tests/golden/metrics.npz,
+stack.npz) and the oracle.  Tolerance for metric scalars: rel 1e-5 unless the quantity is a
+width interpolated between float32 autocorrelation samples (rel 2e-5, stated where used)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from barc4dip_amd import synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import torch
+
+    assert torch.cuda.is_available()
+    from barc4dip_amd import metrics
+
+    return metrics
+
+
+def _kat_image(n=512):
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[-n // 2:n // 2, -n // 2:n // 2]
+    pupil = (xx ** 2 + yy ** 2) <= (n / 16) ** 2
+    field = np.fft.ifft2(np.fft.ifftshift(pupil * np.exp(2j * np.pi * rng.random((n, n)))))
+    img = np.abs(field) ** 2
+    return (img / img.mean() * 1000).astype(np.float32)
+
+
+def _walk(prefix, d, g, rtol, seen, skip=()):
+    for k, v in d.items():
+        key = f"{prefix}/{k}"
+        if isinstance(v, dict):
+            _walk(key, v, g, rtol, seen, skip)
+        elif key in g.files and g[key].dtype.kind not in "US" and not any(s in key for s in skip):
+            np.testing.assert_allclose(np.asarray(v, dtype=float), g[key], rtol=rtol, atol=1e-12, equal_nan=True, err_msg=key)
+            seen.append(key)
+
+
+@pytest.mark.parametrize("tag", ["kat512", "poisson512"])
+@pytest.mark.parametrize("origin", ["lower", "upper"])
+def test_aggregators_vs_reference_golden(gm, golden, tag, origin):
+    g = golden("metrics.npz")
+    img = _kat_image() if tag == "kat512" else synth.speckle_frame(512, 1234)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        sp = gm.speckle_stats(img, display_origin=origin, verbose=False)
+        sh = gm.sharpness_stats(img, display_origin=origin, verbose=False)
+    assert any("general-length" in str(w.message) for w in wlist)        # 170/171-px FFT tiles are skipped, loudly
+    ac = sp["full"]["grain"].pop("autocorr")
+    assert ac.dtype == np.float64 and ac[256, 256] == 1.0
+    np.testing.assert_allclose(ac[256, :], g[f"{tag}/{origin}/speckle/full/grain/autocorr_cut_x"], atol=1e-5)
+    seen = []
+    _walk(f"{tag}/{origin}/speckle", sp, g, 2e-5, seen)
+    _walk(f"{tag}/{origin}/sharpness", sh, g, 2e-5, seen)
+    assert len(seen) > 45, len(seen)
+    # schema: same keys as the reference for everything we return
+    assert set(sp["full"]) == {"amplitude", "grain", "stats", "bandwidth"}
+    assert set(sh["full"]) == {"stats", "gradient", "laplacian", "spectral", "autocorrelation", "eigenvalues"}
+    assert sp["meta"]["tile_mode"] == "tiles_3x3" and sp["tiles"]["amplitude"]["visibility"]["mean"].shape == (3, 3)
+    assert np.isnan(sp["tiles"]["stats"]["mean"]["std"]).all()
+
+
+def test_survey_kats(gm):
+    img = _kat_image()
+    a = gm.speckles.amplitude(img)
+    assert a["visibility"] == pytest.approx(0.9955749775726361, rel=1e-9)
+    assert a["contrast"] == pytest.approx(0.9998632364734213, rel=1e-9)
+    gr = gm.speckles.grain(img)
+    assert gr["lx"] == pytest.approx(9.690115608100314, rel=2e-5)
+    assert gr["ly"] == pytest.approx(9.660333123945321, rel=2e-5)
+    assert gr["leq"] == pytest.approx(9.663208059536487, rel=2e-5)
+    bw = gm.speckles.bandwidth(img)
+    assert bw["feq"] == pytest.approx(0.06289603897556885, rel=RTOL)
+    assert bw["f95"] == pytest.approx(0.10150614422020533, rel=1e-12)
+    assert bw["sig_fx"] == pytest.approx(0.0444001234334224, rel=RTOL)
+    assert bw["spr"] == pytest.approx(3621.6068899820348, rel=RTOL)
+    assert gm.sharpness.tenengrad(img)["tenengrad"] == pytest.approx(8973629.89178935, rel=1e-10)
+    assert gm.sharpness.laplacian_variance(img) == pytest.approx(38699.84234914002, rel=1e-9)
+    assert gm.sharpness.spectral_entropy(img) == pytest.approx(0.6911419299004048, rel=RTOL)
+    iw = gm.sharpness.inverse_autocorr_width(img)
+    assert iw["sx"] == pytest.approx(0.10319794318697956, rel=2e-5)
+    assert iw["seq"] == pytest.approx(0.10348530155191205, rel=2e-5)
+    e = gm.sharpness.eigenvalues(img)
+    assert e["eigenvalues"] == pytest.approx(4.2286742100154455e-07, rel=1e-6)
+    dm = gm.distribution_moments(img)
+    assert dm["skewness"] == pytest.approx(2.0379286254969116, rel=1e-10)
+    assert dm["kurtosis"] == pytest.approx(6.426728078998179, rel=1e-10)
+
+
+def test_percentiles_and_radial_vs_numpy(gm):
+    from oracle import metrics_np as M
+    from oracle import signal_np as S
+
+    frames = np.stack([synth.speckle_frame(256, 3)[:171, :200], synth.speckle_frame(256, 4)[:171, :200]])
+    frames[1, 5, 5] = np.nan
+    q = [0.0, 0.05, 50.0, 99.95, 100.0]
+    got = gm.kernels.percentiles_batch(frames, q)
+    ref = np.stack([np.nanpercentile(f.astype(np.float64), q) for f in frames])
+    np.testing.assert_allclose(got, ref, rtol=1e-12)
+    acs = S.autocorr2d(synth.speckle_frame(128, 5))[0]
+    prof, r = gm.__dict__["kernels"] and __import__("barc4dip_amd.maths", fromlist=["x"]).radial_mean_interpolated(acs.astype(np.float32))
+    pr, rr = M.radial_mean_interpolated(acs.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(prof, pr, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(r, rr)
+
+
+def test_errors_match_reference(gm):
+    img = synth.speckle_frame(512, 1)
+    with pytest.raises(TypeError):
+        gm.speckle_stats([[1.0]])
+    with pytest.raises(ValueError):
+        gm.speckle_stats(img[0])
+    with pytest.raises(ValueError):
+        gm.speckle_stats(img, metrics="bogus", verbose=False)
+    with pytest.raises(ValueError):
+        gm.speckles.grain(img[:100, :100])
+    with pytest.raises(ValueError):
+        gm.speckles.amplitude(-img)
+    with pytest.raises(ValueError):
+        gm.sharpness.spectral_entropy(np.where(img > 5000, np.nan, img))
+    with pytest.raises(TypeError):
+        gm.sharpness_stack_stats(img.tolist())
+    with pytest.raises(ImportError):
+        gm.speckle_stack_stats(img[None], verbose=False)           # default tracker needs scikit-image, like the reference
+    with pytest.warns(RuntimeWarning):
+        out = gm.speckle_stats(img[:300, :300].copy(), metrics="stats", verbose=False)   # too small for tiles
+    assert "tiles" not in out
+
+
+def test_stack_stats_vs_reference_golden(gm, golden):
+    g = golden("stack.npz")
+    stack, sh = synth.shifted_stack(5, 384, seed=1234, max_shift=12)
+    assert not __import__("barc4dip_amd")._ffi.supported(384, 384)
+    with pytest.raises(NotImplementedError):                       # 384 is not a native FFT size: loud, no fallback
+        gm.speckle_stack_stats(stack, metrics=("amplitude", "grain", "stats"), tracking_method="phase",
+                               tracking_backend="internal", verbose=False)
+    res2 = gm.sharpness_stack_stats(stack[:3], metrics=("gradient", "laplacian"), verbose=False)
+    seen = []
+    _walk("sharpness", {k: res2[k] for k in ("full", "tiles")}, g, 1e-9, seen)
+    assert len(seen) >= 10
+    # same protocol on a native size against the oracle (temporal block + per-frame series)
+    from oracle import metrics_np as M
+
+    stack2, sh2 = synth.shifted_stack(4, 512, seed=77, max_shift=10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = gm.speckle_stack_stats(stack2, metrics=("amplitude", "stats"), tiles=True, roi_grain_factor=24.0,
+                                     tracking_method="phase", tracking_backend="internal", verbose=False)
+        ref = M.speckle_stack_stats(stack2, metrics=("amplitude", "stats"), tiles=True, roi_grain_factor=24.0,
+                                    tracking_method="phase", tracking_backend="internal")
+    assert got["meta"]["tracking"]["roi_size_yx"] == ref["meta"]["tracking"]["roi_size_yx"]
+    for blk in ("abs", "inc"):
+        for k in ("dx", "dy", "r"):
+            np.testing.assert_allclose(got["temporal"][blk][k], ref["temporal"][blk][k], atol=5e-3)
+        assert got["temporal"][blk]["dx"].dtype == np.float32 and got["temporal"][blk]["dx"].shape == (4,)
+    np.testing.assert_allclose(got["temporal"]["abs"]["dy"], sh2[:, 0], atol=0.2)
+    np.testing.assert_allclose(got["full"]["amplitude"]["visibility"], ref["full"]["amplitude"]["visibility"], rtol=1e-9)
+    np.testing.assert_allclose(got["tiles"]["stats"]["mean"]["mean"], ref["tiles"]["stats"]["mean"]["mean"], rtol=1e-10)
