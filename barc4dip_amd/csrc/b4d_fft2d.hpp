@@ -176,8 +176,13 @@ struct ColArgs {
 //   NY == 4096: NC = 2, CPT = 4 -> CT = 8; 1024 lanes (a 16-column tile would need the whole register file)
 template <int NY>
 struct ColCfg {
+#ifdef B4D_COL2048_1024   // experiment: 1024 lanes x 2 columns at NY = 2048 (16 waves, 128-VGPR cap)
+    static constexpr int NC = (NY == 4096 || NY == 2048) ? 2 : 4;
+    static constexpr int CPT = NY == 2048 ? 8 : 4;
+#else
     static constexpr int NC = NY == 4096 ? 2 : 4;
     static constexpr int CPT = 4;
+#endif
     static constexpr int CT = NC * CPT;
     static constexpr int THREADS = CPT * (NY / E16);
     using G = ColGeom<NY, CPT>;
@@ -571,9 +576,26 @@ struct b4d_plan {
     size_t ws_bytes = 0;
     void* track_ws = nullptr;  // lazily grown arena of the xcorr / tracking entry points
     size_t track_bytes = 0;
+    // general-length plans (b4d_general.hip): dense DFT matrices + three chunk-sized complex buffers
+    bool general = false;
+    float2* wx = nullptr;
+    float2* wy = nullptr;
+    float2* gbuf1 = nullptr;
+    float2* gbuf2 = nullptr;
+    float2* gbuf3 = nullptr;
 };
 
+// b4d_general.hip
+int make_dft_matrix(int n, float2** out);
+int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* psd, float psd_scale, float* autocorr,
+                         unsigned flags, hipStream_t st);
+int general_fft2d(b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st);
+int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, hipStream_t st);
+// b4d_track.hip: x[b] /= max|x[b]| for `batch` maps of n floats; scratch holds >= 256 * batch floats
+int normalise_by_absmax(float* x, size_t n, int batch, float* scratch, hipStream_t st);
+
 static inline bool pow2_ok(int n) { return n >= 64 && n <= 4096 && (n & (n - 1)) == 0; }
+static inline bool general_ok(int n) { return n >= 2 && n <= 512; }
 
 static inline int make_twiddles(int n, float2** out) {
     std::vector<float2> h(n);

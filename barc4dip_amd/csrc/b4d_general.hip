@@ -1,0 +1,234 @@
+// b4d_general.hip -- general-length 2-D transforms (any 2 <= ny, nx <= 512) as dense DFT-matrix products.
+//
+// The aggregators of barc4dip evaluate every metric on 3x3 tiles or 9x9 sub-tiles (metrics/common.py:75-106,
+// 278-378): 170/171-pixel tiles at 512^2, 227/228 at 2048^2 -- sizes with large prime factors (19, 227).  For these
+// small, awkward lengths the 2-D DFT is evaluated as F = Wy * X * Wx with precomputed DFT matrices: a genuinely
+// dense contraction (the one place on this path where that appears), regular, any length, float32-exact FMA
+// chains.  O(n^3) per transform keeps it to n <= 512; power-of-two frames never come here (b4d_fft2d.hpp).
+// The product kernel is a plain LDS-tiled complex GEMM on the vector ALUs (64x64 tile, 4x4 register block);
+// moving it to v_mfma_f32_32x32x2_f32 is listed in DESIGN.md §8.
+#include "b4d_fft2d.hpp"
+
+namespace b4d {
+
+struct GemmArgs {
+    const void* A;   // (M, K) row-major, float or float2
+    const void* B;   // (K, N) row-major, float or float2
+    float2* C;       // (M, N) row-major
+    int M, N, K;
+    long long sA, sB, sC;  // batch strides in elements (0 = shared operand)
+    int conj_a, conj_b;
+};
+
+template <bool REAL>
+__device__ __forceinline__ float2 ld_elem(const void* p, long long i, int conj) {
+    if (REAL) return make_float2(static_cast<const float*>(p)[i], 0.f);
+    const float2 v = static_cast<const float2*>(p)[i];
+    return conj ? make_float2(v.x, -v.y) : v;
+}
+
+// grid (ceil(N/64), ceil(M/64), batch), block 256 = 16 x 16 lanes, 4 x 4 complex outputs per lane
+template <bool AREAL, bool BREAL>
+__global__ void __launch_bounds__(256) k_cgemm(GemmArgs g) {
+    __shared__ float2 As[16][65];  // [k][m]
+    __shared__ float2 Bs[16][65];  // [k][n]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const long long oa = (long long)blockIdx.z * g.sA, ob = (long long)blockIdx.z * g.sB, oc = (long long)blockIdx.z * g.sC;
+    float2 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = make_float2(0.f, 0.f);
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = threadIdx.x + 256 * r;  // 0..1023
+            {   // A tile: 64 rows x 16 k, k fastest in memory
+                const int kk = e & 15, mm = e >> 4;
+                const int m = m0 + mm, k = k0 + kk;
+                As[kk][mm] = (m < g.M && k < g.K) ? ld_elem<AREAL>(g.A, oa + (long long)m * g.K + k, g.conj_a) : make_float2(0.f, 0.f);
+            }
+            {   // B tile: 16 k x 64 cols, n fastest in memory
+                const int nn = e & 63, kk = e >> 6;
+                const int n = n0 + nn, k = k0 + kk;
+                Bs[kk][nn] = (n < g.N && k < g.K) ? ld_elem<BREAL>(g.B, ob + (long long)k * g.N + n, g.conj_b) : make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float2 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j].x = fmaf(a[i].x, b[j].x, fmaf(-a[i].y, b[j].y, acc[i][j].x));
+                    acc[i][j].y = fmaf(a[i].x, b[j].y, fmaf(a[i].y, b[j].x, acc[i][j].y));
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n < g.N) g.C[oc + (long long)m * g.N + n] = acc[i][j];
+        }
+    }
+}
+
+// ---- elementwise epilogues (one lane per pixel; grid (ceil(npix/256), batch))
+__global__ void __launch_bounds__(256) k_gen_power(const float2* __restrict__ F, int ny, int nx, float* __restrict__ psd,
+                                                   float scale, float* __restrict__ P, unsigned flags) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * nx) return;
+    const size_t fo = (size_t)blockIdx.y * ny * nx;
+    const int ky = e / nx, kx = e % nx;
+    const float2 f = F[fo + e];
+    const float p = f.x * f.x + f.y * f.y;
+    if (psd) psd[fo + (size_t)((ky + ny / 2) % ny) * nx + (kx + nx / 2) % nx] = p * scale;
+    if (P) P[fo + e] = (e == 0 && (flags & B4D_REMOVE_MEAN)) ? 0.f : p;
+}
+
+__global__ void __launch_bounds__(256) k_gen_shift_c(const float2* __restrict__ F, int ny, int nx, float2* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * nx) return;
+    const size_t fo = (size_t)blockIdx.y * ny * nx;
+    const int ky = e / nx, kx = e % nx;
+    out[fo + (size_t)((ky + ny / 2) % ny) * nx + (kx + nx / 2) % nx] = F[fo + e];
+}
+
+__global__ void __launch_bounds__(256) k_gen_cross(const float2* __restrict__ Fa, const float2* __restrict__ Fb, int npix,
+                                                   float2* __restrict__ C, unsigned flags) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npix) return;
+    const size_t fo = (size_t)blockIdx.y * npix;
+    float2 c = cross_power<false>(Fa[fo + e], Fb[fo + e], 0.f);
+    if (e == 0 && (flags & B4D_REMOVE_MEAN)) c = make_float2(0.f, 0.f);
+    C[fo + e] = c;
+}
+
+// real part of the inverse transform, shifted; NORM_PEAK: divided by the zero-lag value (exactly 1 there)
+__global__ void __launch_bounds__(256) k_gen_real_out(const float2* __restrict__ R, int ny, int nx, float* __restrict__ out,
+                                                      float scale, unsigned flags) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * nx) return;
+    const size_t fo = (size_t)blockIdx.y * ny * nx;
+    const int y = e / nx, x = e % nx;
+    float s = scale;
+    const bool norm = (flags & B4D_NORM_PEAK) != 0;
+    if (norm) {
+        const float pk = R[fo].x;
+        s = pk != 0.f ? 1.0f / pk : 1.0f;
+    }
+    float v = R[fo + e].x * s;
+    if (norm && e == 0) v = 1.0f;
+    out[fo + (size_t)((y + ny / 2) % ny) * nx + (x + nx / 2) % nx] = v;
+}
+
+}  // namespace b4d
+
+using namespace b4d;
+
+static int cgemm(const void* A, bool a_real, long long sA, int conj_a, const void* B, bool b_real, long long sB, int conj_b,
+                 float2* C, long long sC, int M, int N, int K, int batch, hipStream_t st) {
+    GemmArgs g{A, B, C, M, N, K, sA, sB, sC, conj_a, conj_b};
+    const dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+    if (a_real && !b_real)
+        hipLaunchKernelGGL((k_cgemm<true, false>), grid, dim3(256), 0, st, g);
+    else if (!a_real && !b_real)
+        hipLaunchKernelGGL((k_cgemm<false, false>), grid, dim3(256), 0, st, g);
+    else
+        return fail(B4D_EINVAL, "cgemm: unsupported operand types");
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+// DFT matrix W[j][k] = exp(-2 pi i (j k mod n) / n), float64 on the host
+int make_dft_matrix(int n, float2** out) {
+    std::vector<float2> h((size_t)n * n);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < n; ++k) {
+            const double a = -2.0 * M_PI * (double)(((long long)j * k) % n) / (double)n;
+            h[(size_t)j * n + k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    B4D_HIP(hipMalloc((void**)out, sizeof(float2) * h.size()));
+    B4D_HIP(hipMemcpy(*out, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
+    return B4D_OK;
+}
+
+// F[b] = Wy * (X[b] * Wx)   (inverse: conjugated matrices, no 1/(nx ny))
+static int dft2(const b4d_plan* pl, const void* X, bool x_real, int batch, int conj, float2* tmp, float2* F, hipStream_t st) {
+    const int ny = pl->ny, nx = pl->nx;
+    const long long fp = (long long)ny * nx;
+    int rc = cgemm(X, x_real, fp, 0, pl->wx, false, 0, conj, tmp, fp, ny, nx, nx, batch, st);
+    if (rc) return rc;
+    return cgemm(pl->wy, false, 0, conj, tmp, false, fp, 0, F, fp, ny, nx, ny, batch, st);
+}
+
+int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* psd, float psd_scale, float* autocorr,
+                         unsigned flags, hipStream_t st) {
+    const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
+    const dim3 eg((npix + 255) / 256, 1);
+    for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
+        const int nb = std::min(pl->chunk, batch - b0);
+        const size_t off = (size_t)b0 * npix;
+        int rc = dft2(pl, frames + off, true, nb, 0, pl->gbuf1, pl->gbuf2, st);
+        if (rc) return rc;
+        float* P = reinterpret_cast<float*>(pl->gbuf1);  // gbuf1 is free again: power spectrum (real)
+        hipLaunchKernelGGL(k_gen_power, dim3(eg.x, nb), dim3(256), 0, st, pl->gbuf2, ny, nx, psd ? psd + off : nullptr, psd_scale,
+                           autocorr ? P : nullptr, flags);
+        B4D_HIP(hipGetLastError());
+        if (!autocorr) continue;
+        // inverse of the REAL power spectrum: tmp = P * conj(Wx) lands in gbuf2, result in gbuf3
+        const long long fp = npix;
+        if ((rc = cgemm(P, true, fp, 0, pl->wx, false, 0, 1, pl->gbuf2, fp, ny, nx, nx, nb, st))) return rc;
+        if ((rc = cgemm(pl->wy, false, 0, 1, pl->gbuf2, false, fp, 0, pl->gbuf3, fp, ny, nx, ny, nb, st))) return rc;
+        hipLaunchKernelGGL(k_gen_real_out, dim3(eg.x, nb), dim3(256), 0, st, pl->gbuf3, ny, nx, autocorr + off,
+                           1.0f / ((float)nx * (float)ny), flags);
+        B4D_HIP(hipGetLastError());
+    }
+    return B4D_OK;
+}
+
+int general_fft2d(b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st) {
+    const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
+    for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
+        const int nb = std::min(pl->chunk, batch - b0);
+        int rc = dft2(pl, frames + (size_t)b0 * npix, true, nb, 0, pl->gbuf1, pl->gbuf2, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gen_shift_c, dim3((npix + 255) / 256, nb), dim3(256), 0, st, pl->gbuf2, ny, nx, out + (size_t)b0 * npix);
+        B4D_HIP(hipGetLastError());
+    }
+    return B4D_OK;
+}
+
+int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, hipStream_t st) {
+    const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
+    const long long fp = npix;
+    for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
+        const int nb = std::min(pl->chunk, batch - b0);
+        const size_t off = (size_t)b0 * npix;
+        int rc = dft2(pl, a + off, true, nb, 0, pl->gbuf1, pl->gbuf2, st);
+        if (rc) return rc;
+        if ((rc = dft2(pl, b + off, true, nb, 0, pl->gbuf1, pl->gbuf3, st))) return rc;
+        hipLaunchKernelGGL(k_gen_cross, dim3((npix + 255) / 256, nb), dim3(256), 0, st, pl->gbuf2, pl->gbuf3, npix, pl->gbuf2, flags);
+        B4D_HIP(hipGetLastError());
+        if ((rc = cgemm(pl->gbuf2, false, fp, 0, pl->wx, false, 0, 1, pl->gbuf1, fp, ny, nx, nx, nb, st))) return rc;
+        if ((rc = cgemm(pl->wy, false, 0, 1, pl->gbuf1, false, fp, 0, pl->gbuf3, fp, ny, nx, ny, nb, st))) return rc;
+        hipLaunchKernelGGL(k_gen_real_out, dim3((npix + 255) / 256, nb), dim3(256), 0, st, pl->gbuf3, ny, nx, corr + off,
+                           1.0f / ((float)nx * (float)ny), 0u);
+        B4D_HIP(hipGetLastError());
+        if (flags & B4D_NORM_PEAK)
+            if ((rc = normalise_by_absmax(corr + off, (size_t)npix, nb, reinterpret_cast<float*>(pl->gbuf1), st))) return rc;
+    }
+    return B4D_OK;
+}

@@ -13,19 +13,38 @@ extern "C" {
 
 const char* b4d_version(void) { return "b4d 0.1.0 (gfx950)"; }
 const char* b4d_last_error(void) { return last_error().c_str(); }
-int b4d_size_supported(int ny, int nx) { return pow2_ok(ny) && pow2_ok(nx); }
+int b4d_size_supported(int ny, int nx) { return (pow2_ok(ny) && pow2_ok(nx)) || (general_ok(ny) && general_ok(nx)); }
 
 int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out) {
     if (!out) return fail(B4D_EINVAL, "out is null");
     *out = nullptr;
     if (!b4d_size_supported(ny, nx))
-        return fail(B4D_ESIZE, "native plans need power-of-two ny, nx in [64, 4096]; got " + std::to_string(ny) + "x" +
-                                   std::to_string(nx));
+        return fail(B4D_ESIZE, "plans need power-of-two ny, nx in [64, 4096] (FFT kernels) or any ny, nx in [2, 512] "
+                               "(DFT-matrix path); got " + std::to_string(ny) + "x" + std::to_string(nx));
     if (chunk < 1) return fail(B4D_EINVAL, "chunk must be >= 1");
     b4d_plan* p = new b4d_plan();
     p->ny = ny;
     p->nx = nx;
     p->chunk = chunk;
+    if (!(pow2_ok(ny) && pow2_ok(nx))) {  // general-length plan
+        p->general = true;
+        int rc = make_dft_matrix(nx, &p->wx);
+        if (rc == B4D_OK) rc = make_dft_matrix(ny, &p->wy);
+        if (rc != B4D_OK) {
+            b4d_plan_destroy(p);
+            return rc;
+        }
+        p->ws_bytes = 3 * sizeof(float2) * (size_t)chunk * ny * nx;
+        hipError_t e = hipMalloc((void**)&p->gbuf1, p->ws_bytes / 3);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->gbuf2, p->ws_bytes / 3);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->gbuf3, p->ws_bytes / 3);
+        if (e != hipSuccess) {
+            b4d_plan_destroy(p);
+            return fail(B4D_ENOMEM, std::string("workspace allocation failed: ") + hipGetErrorString(e));
+        }
+        *out = p;
+        return B4D_OK;
+    }
     p->ct_w = (ny == 4096) ? 8 : 16;
     int rc = make_twiddles(nx, &p->tw_x);
     if (rc == B4D_OK) rc = make_twiddles(ny, &p->tw_y);
@@ -55,6 +74,8 @@ int b4d_plan_destroy(b4d_plan* p) {
     if (p->nyq_rows) (void)hipFree(p->nyq_rows);
     if (p->gnyq) (void)hipFree(p->gnyq);
     if (p->track_ws) (void)hipFree(p->track_ws);
+    for (float2* q : {p->wx, p->wy, p->gbuf1, p->gbuf2, p->gbuf3})
+        if (q) (void)hipFree(q);
     delete p;
     return B4D_OK;
 }
@@ -74,6 +95,7 @@ static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float
     if (!pl || !frames) return fail(B4D_EINVAL, "null plan or input");
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
     if (!psd && !autocorr) return fail(B4D_EINVAL, "both outputs are null");
+    if (pl->general) return general_psd_autocorr(pl, frames, batch, psd, psd_scale, autocorr, flags, st);
     const size_t fpix = (size_t)pl->ny * pl->nx;
     std::vector<hipEvent_t> ev;
     auto mark = [&]() -> int {
@@ -175,6 +197,7 @@ int b4d_fft2d(b4d_plan* pl, const float* frames, int batch, float* out_c64, void
     if (!pl || !frames || !out_c64) return fail(B4D_EINVAL, "null argument");
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
     hipStream_t st = (hipStream_t)stream;
+    if (pl->general) return general_fft2d(pl, frames, batch, reinterpret_cast<float2*>(out_c64), st);
     const size_t fpix = (size_t)pl->ny * pl->nx;
     for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
         const int nb = std::min(pl->chunk, batch - b0);

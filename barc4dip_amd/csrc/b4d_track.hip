@@ -327,12 +327,20 @@ static int product_inverse(const b4d_plan* pl, const float2* spec, const float2*
     return dispatch_nyq<WHITEN ? NYQ_PROD_WHITEN : NYQ_PROD>(pl, na, pairs, st);
 }
 
+int normalise_by_absmax(float* x, size_t n, int batch, float* scratch, hipStream_t st) {
+    hipLaunchKernelGGL(k_absmax_part, dim3(256, batch), dim3(1024), 0, st, x, n, scratch);
+    hipLaunchKernelGGL(k_scale_by_max, dim3(1024, batch), dim3(256), 0, st, x, n, scratch, 256);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
 extern "C" {
 
 int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, void* stream) {
     if (!pl || !a || !b || !corr) return fail(B4D_EINVAL, "null argument");
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
     hipStream_t st = (hipStream_t)stream;
+    if (pl->general) return general_xcorr(pl, a, b, batch, corr, flags, st);
     const size_t fpix = (size_t)pl->ny * pl->nx, half = fpix / 2, ny = pl->ny;
     const int chunk = pl->chunk;
     size_t need = 0;
@@ -368,11 +376,8 @@ int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* 
         ra.ct_w = pl->ct_w;
         ra.flags = 0;
         if ((rc = dispatch_c2r(pl, ra, nb, st, C2R_OUT))) return rc;
-        if (flags & B4D_NORM_PEAK) {
-            hipLaunchKernelGGL(k_absmax_part, dim3(256, nb), dim3(1024), 0, st, corr + b0 * fpix, fpix, part);
-            hipLaunchKernelGGL(k_scale_by_max, dim3(1024, nb), dim3(256), 0, st, corr + b0 * fpix, fpix, part, 256);
-            B4D_HIP(hipGetLastError());
-        }
+        if (flags & B4D_NORM_PEAK)
+            if ((rc = normalise_by_absmax(corr + b0 * fpix, fpix, nb, part, st))) return rc;
     }
     return B4D_OK;
 }
@@ -384,6 +389,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     if (!pl || !images || !tpl_src || !tpl_frame || !tpl_roi || !pair_img || !pair_tpl || !out)
         return fail(B4D_EINVAL, "null argument");
     if (nimg < 1 || ntplsrc < 1 || ntpl < 1 || npairs < 1) return fail(B4D_EINVAL, "counts must be >= 1");
+    if (pl->general) return fail(B4D_ESIZE, "phase correlation needs power-of-two ny, nx in [64, 4096]");
     const int ny = pl->ny, nx = pl->nx;
     for (int k = 0; k < ntpl; ++k) {
         const int32_t* r = tpl_roi + 4 * k;

@@ -223,7 +223,7 @@ def sharpness_stats(image: np.ndarray, *, metrics: str | Sequence[str] = "all", 
     fft_groups = sorted(groups & _FFT_GROUPS)
     if fft_groups:
         n, ys, xs = tile_spans(h, w, mode)
-        if all(_fft_ok((y1 - y0, x1 - x0)) and (y1 - y0) == (x1 - x0) for y0, y1 in ys for x0, x1 in xs):
+        if all(_fft_ok((y1 - y0, x1 - x0)) for y0, y1 in ys for x0, x1 in xs):
             if "spectral" in groups:
                 tiles_out["spectral"] = tiled_scalar_fields(t, tile_mode=mode, compute_fn=lambda v: {"spectral_entropy": spectral_entropy(v)})
             if "autocorrelation" in groups:

@@ -66,7 +66,7 @@ def _pad_square_dev(t):
 
 def _fft_ok(shape) -> bool:
     n = max(shape)
-    return _ffi.supported(n, n)
+    return _ffi.supported(n, n) and _ffi.supported(int(shape[0]), int(shape[1]))
 
 
 def _amplitude_from(mom_row, pct_row) -> dict:

@@ -41,6 +41,7 @@ def test_no_gpu_calls_needed_for_introspection(lib):
     assert lib.b4d_size_supported(2048, 2048) == 1
     assert lib.b4d_size_supported(64, 4096) == 1
     assert lib.b4d_size_supported(100, 2048) == 0
+    assert lib.b4d_size_supported(171, 170) == 1 and lib.b4d_size_supported(513, 100) == 0
     assert lib.b4d_size_supported(8192, 2048) == 0
     assert lib.b4d_plan_destroy(None) == 0
 

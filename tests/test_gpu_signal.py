@@ -111,10 +111,10 @@ def test_errors(gs):
         gs.autocorr2d(np.zeros((512, 512), dtype=np.float32), normalize="bogus")
     with pytest.raises(ValueError):
         gs.autocorr2d(np.zeros((4, 512, 512), dtype=np.float32))
-    with pytest.raises(NotImplementedError):           # no CPU fallback for sizes without a native plan
-        gs.psd2d(np.zeros((100, 100), dtype=np.float32))
+    with pytest.raises(NotImplementedError):           # no CPU fallback for sizes without a plan
+        gs.psd2d(np.zeros((600, 600), dtype=np.float32))
     with pytest.raises(NotImplementedError):
-        gs.autocorr2d(np.zeros((32, 64), dtype=np.float32))
+        gs.autocorr2d(np.zeros((1000, 2048), dtype=np.float32))
     with pytest.raises(NotImplementedError):
         gs.fft2d(np.zeros((512, 512), dtype=np.complex64))
 
@@ -204,3 +204,38 @@ def test_golden_reference_vectors_64(gs, golden):
     assert nerr(gs.autocorr2d(a, standardize=True, normalize="none")[0], g["f32_64/autocorr2d_rm1_st1_none"]) < TOL
     assert nerr(gs.xcorr2d(a, b)[0], np.real(g["f32_64/xcorr2d_rm1_st0_peak"])) < TOL
     assert nerr(gs.xcorr2d(a, b, standardize=True, normalize="none")[0], np.real(g["f32_64/xcorr2d_rm1_st1_none"])) < TOL
+
+
+@pytest.mark.parametrize("shape", [(171, 170), (228, 227), (100, 100), (33, 45), (32, 512), (2, 3)])
+def test_general_lengths_vs_oracle(gs, shape):
+    """Any ny, nx <= 512: DFT-matrix plans (the aggregators' 170/171- and 227/228-pixel tiles)."""
+    from oracle import signal_np as S
+
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    img = (rng.poisson(200.0, size=shape) + 5 * rng.random(shape)).astype(np.float32)
+    b = (np.roll(img, (1, -1), axis=(0, 1)) * 0.9 + rng.random(shape)).astype(np.float32)
+    r64 = img.astype(np.float64)
+    assert nerr(gs.fft2d(img)[0], S.fft2d(r64)[0]) < TOL
+    assert nerr(gs.psd2d(img, dx=0.5, dy=2.0)[0], S.psd2d(r64, dx=0.5, dy=2.0)[0]) < TOL
+    for kw in (dict(), dict(remove_mean=False, normalize="none"), dict(standardize=True, normalize="none")):
+        assert nerr(gs.autocorr2d(img, **kw)[0], S.autocorr2d(r64, **kw)[0]) < TOL
+        assert nerr(gs.xcorr2d(img, b, **kw)[0], np.real(S.xcorr2d(r64, b.astype(np.float64), **kw)[0])) < TOL
+    ac = gs.autocorr2d(img)[0]
+    assert ac[shape[0] // 2, shape[1] // 2] == 1.0 and int(np.argmax(ac)) == (shape[0] // 2) * shape[1] + shape[1] // 2
+
+
+@pytest.mark.parametrize("name", ["f64_24x32", "f32_32x16", "f64_17x23"])
+def test_golden_reference_vectors_small(gs, golden, name):
+    """The small dense cases captured from the REAL reference (odd, non-square, float64 inputs)."""
+    g = golden("signal_small.npz")
+    a, b = g[f"{name}/a"], g[f"{name}/b"]
+    assert nerr(gs.fft2d(a, dx=0.5, dy=2.0)[0], g[f"{name}/fft2d"]) < TOL
+    assert nerr(gs.psd2d(a)[0], g[f"{name}/psd2d"]) < TOL
+    assert nerr(gs.psd2d(a, scale=False)[0], g[f"{name}/psd2d_noscale"]) < TOL
+    for rm in (True, False):
+        for st in (True, False):
+            for nm in ("peak", "none"):
+                tag = f"rm{int(rm)}_st{int(st)}_{nm}"
+                kw = dict(remove_mean=rm, standardize=st, normalize=nm)
+                assert nerr(gs.autocorr2d(a, **kw)[0], g[f"{name}/autocorr2d_{tag}"]) < TOL, tag
+                assert nerr(gs.xcorr2d(a, b, **kw)[0], np.real(g[f"{name}/xcorr2d_{tag}"])) < TOL, tag

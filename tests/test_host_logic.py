@@ -83,3 +83,4 @@ def test_default_chunk_policy():
     assert _ffi.default_chunk(4096, 4096) == 16
     assert _ffi.default_chunk(1024, 1024) == 128
     assert 1 <= _ffi.default_chunk(64, 64) <= 128
+    assert _ffi.default_chunk(228, 227) == 128 and _ffi.default_chunk(512, 500) >= 32

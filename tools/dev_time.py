@@ -8,12 +8,23 @@ sys.path.insert(0, ".")
 from barc4dip_amd import _ffi, synth  # noqa: E402
 
 
+LIBPATH = None
+
+
 def run(T, n, chunk, psd_on=True, ac_on=True, steps=5, flags=3):
     stack = synth.speckle_stack_device(T, n)
     psd = torch.empty_like(stack) if psd_on else None
     ac = torch.empty_like(stack) if ac_on else None
-    pl = _ffi.Plan(n, n, chunk)
-    lib = _ffi.lib()
+    lib = _ffi.load_library(LIBPATH) if LIBPATH else _ffi.lib()
+    h = C.c_void_p()
+    assert lib.b4d_plan_create(n, n, chunk, C.byref(h)) == 0
+
+    class pl:
+        handle = h
+
+        @staticmethod
+        def close():
+            lib.b4d_plan_destroy(h)
     kms = (C.c_float * 4)()
     args = (pl.handle, C.c_void_p(stack.data_ptr()), T, C.c_void_p(psd.data_ptr() if psd_on else 0), 1.0 / (n * n),
             C.c_void_p(ac.data_ptr() if ac_on else 0), flags, _ffi.stream_ptr())
@@ -30,6 +41,11 @@ def run(T, n, chunk, psd_on=True, ac_on=True, steps=5, flags=3):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        LIBPATH = sys.argv[1]
+        run(256, 2048, 64)
+        run(256, 2048, 64, psd_on=False)
+        sys.exit(0)
     run(256, 2048, 32)
     run(256, 2048, 32, psd_on=False)
     run(256, 2048, 32, ac_on=False)
