@@ -148,6 +148,7 @@ struct ColArgs {
     float psd_scale;
     int nx;
     unsigned flags;
+    int half_rows;    // COL_PSD_AC: the consumer uses R[-y,-x] = R[y,x]: only rows 0..ny/2+1 of the tile are stored
 #ifdef B4D_DIAG
     unsigned long long* diag;  // diagnostic build only: 8 s_memtime stamps per workgroup
 #endif
@@ -176,9 +177,12 @@ struct ColArgs {
 //   NY == 4096: NC = 2, CPT = 4 -> CT = 8; 1024 lanes (a 16-column tile would need the whole register file)
 template <int NY>
 struct ColCfg {
-#ifdef B4D_COL2048_1024   // experiment: 1024 lanes x 2 columns at NY = 2048 (16 waves, 128-VGPR cap)
+#if defined(B4D_COL2048_1024)   // experiment: 1024 lanes x 2 columns at NY = 2048 (16 waves, 128-VGPR cap)
     static constexpr int NC = (NY == 4096 || NY == 2048) ? 2 : 4;
     static constexpr int CPT = NY == 2048 ? 8 : 4;
+#elif defined(B4D_COL2048_CT8)  // experiment: 8-column tiles at NY = 2048: 256 lanes, two workgroups per CU
+    static constexpr int NC = NY == 4096 ? 2 : 4;
+    static constexpr int CPT = NY == 2048 ? 2 : 4;
 #else
     static constexpr int NC = NY == 4096 ? 2 : 4;
     static constexpr int CPT = 4;
@@ -353,7 +357,7 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
             c[2 * h] = make_float2(0.5f * (z.x + zr.x), 0.5f * (z.y - zr.y));
             c[2 * h + 1] = make_float2(0.5f * (z.y + zr.y), 0.5f * (zr.x - z.x));
         }
-        store_cols<NC>(tile + (size_t)(T * j * CT) + toff2, c);
+        if (!p.half_rows || u + T * j <= NY / 2 + 1) store_cols<NC>(tile + (size_t)(T * j * CT) + toff2, c);
     }
     B4D_STAMP(6);
     B4D_DRAIN();
@@ -450,6 +454,8 @@ struct RowOutArgs {
     unsigned flags;
     float* part_val;     // C2R_MAG: per-workgroup arg-max partials (batch, gridDim.x)
     int* part_idx;
+    int half;            // C2R_OUT: the map is even (R[-y,-x] = R[y,x], autocorrelation): transform rows 0..ny/2 only
+                         // and write every row together with its point mirror
 };
 
 enum RowOutMode { C2R_OUT = 0, C2R_PEAK = 1, C2R_MAG = 2 };
@@ -475,7 +481,7 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
     const int pair = MODE == C2R_PEAK ? 0 : blockIdx.x * SEQ + seq;
     const size_t frame = blockIdx.y;
     const int ny = p.ny, ct_w = p.ct_w, nt = (NX / 2) / ct_w;
-    const bool live = 2 * pair < ny;
+    const bool live = (MODE == C2R_OUT && p.half) ? 2 * pair <= ny / 2 : 2 * pair < ny;
     const int yl = live ? 2 * pair : 0;
     float2* lds = lds_all + seq * G::LDS_ELEMS;
     float2 v[E];
@@ -514,13 +520,21 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
             const float pk = p.peak[frame];
             s = pk != 0.f ? 1.0f / pk : 1.0f;
         }
+        // half mode: rows 0..ny/2 are written directly, rows 1..ny/2-1 also as their point mirrors
+        const bool wr1 = !p.half || y0 + 1 <= ny / 2;
+        const bool mir0 = p.half && y0 >= 1 && y0 < ny / 2, mir1 = p.half && y0 + 1 < ny / 2;
+        float* q0 = p.out + (frame * ny + ((ny / 2 - y0) & (ny - 1))) * (size_t)NX;
+        float* q1 = p.out + (frame * ny + ((ny / 2 - y0 - 1) & (ny - 1))) * (size_t)NX;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const int x = u + T * j, c = (x + NX / 2) & (NX - 1);
+            const int x = u + T * j, c = (x + NX / 2) & (NX - 1), cm = (NX / 2 - x) & (NX - 1);
             float r0 = v[j].y * s;
+            const float r1 = v[j].x * s;
             if (norm && pair == 0 && x == 0) r0 = 1.0f;  // peak normalisation: zero lag is 1 by definition
             o0[c] = r0;
-            o1[c] = v[j].x * s;
+            if (wr1) o1[c] = r1;
+            if (mir0) q0[cm] = r0;
+            if (mir1) q1[cm] = r1;
         }
         return;
     }
@@ -595,6 +609,20 @@ int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float
 int normalise_by_absmax(float* x, size_t n, int batch, float* scratch, hipStream_t st);
 
 static inline bool pow2_ok(int n) { return n >= 64 && n <= 4096 && (n & (n - 1)) == 0; }
+template <int NY>
+static inline int col_ct_of() { return ColCfg<NY>::CT; }
+static inline int col_ct(int ny) {
+    switch (ny) {
+        case 64: return col_ct_of<64>();
+        case 128: return col_ct_of<128>();
+        case 256: return col_ct_of<256>();
+        case 512: return col_ct_of<512>();
+        case 1024: return col_ct_of<1024>();
+        case 2048: return col_ct_of<2048>();
+        case 4096: return col_ct_of<4096>();
+    }
+    return 16;
+}
 static inline bool general_ok(int n) { return n >= 2 && n <= 512; }
 
 static inline int make_twiddles(int n, float2** out) {
@@ -691,7 +719,8 @@ template <int NX>
 static int launch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, int mode, hipStream_t st,
                       std::vector<hipEvent_t>* ev, int* nblk) {
     constexpr int SEQ = row_seq(NX);
-    const dim3 grid((pl->ny / 2 + SEQ - 1) / SEQ, batch), block((NX / E16) * SEQ);
+    const int npairs = (a.half && mode == C2R_OUT) ? pl->ny / 4 + 1 : pl->ny / 2;
+    const dim3 grid((npairs + SEQ - 1) / SEQ, batch), block((NX / E16) * SEQ);
     if (nblk) *nblk = grid.x;
     if (batch < 1) return B4D_OK;
     if (mode == C2R_MAG) {

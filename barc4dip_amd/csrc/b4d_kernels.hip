@@ -45,7 +45,7 @@ int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out) {
         *out = p;
         return B4D_OK;
     }
-    p->ct_w = (ny == 4096) ? 8 : 16;
+    p->ct_w = col_ct(ny);
     int rc = make_twiddles(nx, &p->tw_x);
     if (rc == B4D_OK) rc = make_twiddles(ny, &p->tw_y);
     if (rc != B4D_OK) {
@@ -119,6 +119,7 @@ static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float
         ca.psd_scale = psd_scale;
         ca.nx = pl->nx;
         ca.flags = flags;
+        ca.half_rows = autocorr ? 1 : 0;   // the autocorrelation is even: K3 transforms rows 0..ny/2 only
 #ifdef B4D_DIAG
         ca.diag = g_diag;
 #endif
@@ -141,6 +142,7 @@ static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float
             ra.ny = pl->ny;
             ra.ct_w = pl->ct_w;
             ra.flags = flags;
+            ra.half = 1;
             if ((rc = dispatch_c2r(pl, ra, nb, st, C2R_OUT, kernel_ms ? &ev : nullptr))) break;
         }
         if ((rc = mark())) break;
