@@ -145,6 +145,8 @@ struct ColArgs {
     float* psd;       // (batch, ny, nx) or null
     float2* full;     // (batch, ny, nx) complex, COL_SPECTRUM only
     const float2* tw;
+    const float2* tw_inv;  // the SAME table through a second, formally unrelated pointer: keeps the compiler from
+                           // holding the forward pass's 30 twiddles in registers (or scratch) for the inverse pass
     float psd_scale;
     int nx;
     unsigned flags;
@@ -170,30 +172,24 @@ struct ColArgs {
 #define B4D_DRAIN() do {} while (0)
 #endif
 
-// Column-tile geometry: a lane holds NC adjacent columns (NC*8 bytes per row), CPT lanes span the tile
-// (CT = NC*CPT columns = whole 128-B lines per row), T = NY/16 lanes run along y.
-//   NY <= 2048: NC = 4, CPT = 4 -> CT = 16; 512 lanes at 2048 (8 waves, up to 256 VGPRs: the 256-KiB tile
-//               sits in registers with room for the butterflies)
-//   NY == 4096: NC = 2, CPT = 4 -> CT = 8; 1024 lanes (a 16-column tile would need the whole register file)
+// Column-tile geometry: a lane holds NC = 2 adjacent columns (one 16-byte load per row), CPT lanes span the
+// tile (CT = NC*CPT columns = whole 128-B lines per row at CT = 16), T = NY/16 lanes run along y.
+//   NY <= 2048: CPT = 8 -> CT = 16; at 2048 the 256-KiB tile lives in the registers of 1024 lanes (16 waves,
+//               <= 128 VGPRs each: 64 of data + butterflies; 4 waves per SIMD hide the LDS / twiddle latencies --
+//               measured 1.23x faster than 512 lanes x 4 columns at 2 waves per SIMD)
+//   NY == 4096: CPT = 4 -> CT = 8 (a 16-column tile would need the whole register file)
+// __launch_bounds__(THREADS, 4) caps every variant at 128 VGPRs so that smaller NY run several workgroups per CU.
 template <int NY>
 struct ColCfg {
-#if defined(B4D_COL2048_1024)   // experiment: 1024 lanes x 2 columns at NY = 2048 (16 waves, 128-VGPR cap)
-    static constexpr int NC = (NY == 4096 || NY == 2048) ? 2 : 4;
-    static constexpr int CPT = NY == 2048 ? 8 : 4;
-#elif defined(B4D_COL2048_CT8)  // experiment: 8-column tiles at NY = 2048: 256 lanes, two workgroups per CU
-    static constexpr int NC = NY == 4096 ? 2 : 4;
-    static constexpr int CPT = NY == 2048 ? 2 : 4;
-#else
-    static constexpr int NC = NY == 4096 ? 2 : 4;
-    static constexpr int CPT = 4;
-#endif
+    static constexpr int NC = 2;
+    static constexpr int CPT = NY == 4096 ? 4 : 8;
     static constexpr int CT = NC * CPT;
     static constexpr int THREADS = CPT * (NY / E16);
+    static constexpr int WAVES_PER_EU = THREADS >= 256 ? 4 : 1;
     using G = ColGeom<NY, CPT>;
-    // sets that share one LDS round trip: 2 wherever two exchange regions fit in the 160 KiB
-    static constexpr int SB = (2 * sizeof(float2) * (size_t)G::LDS_ELEMS * CPT <= 160 * 1024 && NC >= 4) ? 2 : 1;
+    static constexpr int SB = 1;  // sets per LDS round trip (one exchange region = 132 KiB at NY = 2048)
     static constexpr size_t LDS_BYTES = sizeof(float2) * (size_t)G::LDS_ELEMS * CPT * SB;
-    static constexpr bool SERIAL = THREADS > 512;  // at the 128-VGPR cap: pin the per-set order
+    static constexpr bool SERIAL = true;  // at the 128-VGPR cap: pin the per-set order
 };
 
 // 4-byte-aligned 16-byte store (gfx950 runs in unaligned access mode: one global_store_dwordx4)
@@ -210,7 +206,7 @@ __device__ __forceinline__ void store_cols(float2* __restrict__ rowp, const floa
 
 // grid (nt, batch), block ColCfg<NY>::THREADS.
 template <int NY, int MODE>
-__global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
+__global__ void __launch_bounds__(ColCfg<NY>::THREADS, ColCfg<NY>::WAVES_PER_EU) k_col(ColArgs p) {
     using Cfg = ColCfg<NY>;
     using G = typename Cfg::G;
     constexpr int T = G::T, E = E16, NC = Cfg::NC, CPT = Cfg::CPT, CT = Cfg::CT;
@@ -227,10 +223,12 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
     const unsigned toff = (unsigned)u * CT + NC * cp;  // element offset of (row u, first column of this lane)
     float2 v[NC][E];
     B4D_STAMP(0);
+    // column pairs in issue order: the first pair's loads complete first, so its butterflies start while the
+    // second pair is still streaming in (loads return in order; the compiler's counted vmcnt does the rest)
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
+    for (int h = 0; h < NC / 2; ++h) {
 #pragma unroll
-        for (int h = 0; h < NC / 2; ++h) {
+        for (int j = 0; j < E; ++j) {
             const float4 q = *reinterpret_cast<const float4*>(tile + (size_t)(T * j * CT) + toff + 2 * h);
             v[2 * h][j] = make_float2(q.x, q.y);
             v[2 * h + 1][j] = make_float2(q.z, q.w);
@@ -323,14 +321,14 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col(ColArgs p) {
     B4D_DRAIN();
     B4D_STAMP(4);
     if (kx0 == 0 && u == 0 && (p.flags & B4D_REMOVE_MEAN)) w[0][0].y = 0.f;  // DC bin: ky = 0 <-> u = 0, j = 0
-    // Launder pointer/offset: otherwise the compiler keeps the first transform's twiddles and the 64-bit
-    // load addresses alive across the whole kernel (provably identical loads / addresses).
-    const float2* tw2 = p.tw;
-    asm volatile("" : "+s"(tw2));
+    // Launder the offset: otherwise the compiler keeps the 64-bit load addresses alive across the whole kernel.
+    const float2* tw2 = p.tw_inv;
     unsigned toff2 = toff;
     asm volatile("" : "+v"(toff2));
+    int u2 = u, cp2 = cp;   // likewise the ~40 twiddle / LDS byte offsets derived from the lane position
+    asm volatile("" : "+v"(u2), "+v"(cp2));
     __syncthreads();
-    Fft3<G, 1>::template run_sets<NC / 2, Cfg::SERIAL, true, Cfg::SB>(w, u, cp, lds, tw2);
+    Fft3<G, 1>::template run_sets<NC / 2, Cfg::SERIAL, true, Cfg::SB>(w, u2, cp2, lds, tw2);
     B4D_STAMP(5);
     // V[y] = Ga[y] + i Gb[y] with Ga, Gb Hermitian in y: split with V[-y], one set at a time
     float2 vr[NC / 2][E];

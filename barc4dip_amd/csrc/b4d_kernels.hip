@@ -116,6 +116,7 @@ static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float
         ca.spec = pl->spec;
         ca.psd = psd ? psd + b0 * fpix : nullptr;
         ca.tw = pl->tw_y;
+        ca.tw_inv = pl->tw_y;
         ca.psd_scale = psd_scale;
         ca.nx = pl->nx;
         ca.flags = flags;

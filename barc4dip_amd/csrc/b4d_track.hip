@@ -65,7 +65,7 @@ struct ProdArgs {
 
 // grid (nt, pairs), block ColCfg<NY>::THREADS (same tile geometry as k_col).
 template <int NY, bool WHITEN>
-__global__ void __launch_bounds__(ColCfg<NY>::THREADS) k_col_prod(ProdArgs p) {
+__global__ void __launch_bounds__(ColCfg<NY>::THREADS, ColCfg<NY>::WAVES_PER_EU) k_col_prod(ProdArgs p) {
     using Cfg = ColCfg<NY>;
     using G = typename Cfg::G;
     constexpr int T = G::T, E = E16, NC = Cfg::NC, CPT = Cfg::CPT, CT = Cfg::CT;
