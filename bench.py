@@ -34,9 +34,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 def algorithmic_bytes(n: int):
     """Per-frame byte model.  pipe = SURVEY.md §8(d) 4-pass figure (12 N^2 + 40 N Nh);
-    col = what the fused column kernel must move: tile in (8 N N/2) + PSD out (4 N^2) + tile out (8 N N/2)."""
+    col = what the fused column kernel must move: half spectrum in (8 N N/2) + PSD out (4 N^2) + rows 0..N/2+1 of the
+    inverse-column output (8 (N/2+2) N/2; the autocorrelation is even, the other rows are never read)."""
     nh = n // 2 + 1
-    return {"pipe": 12 * n * n + 40 * n * nh, "col": 12 * n * n, "r2c": 8 * n * n, "c2r": 8 * n * n}
+    return {"pipe": 12 * n * n + 40 * n * nh, "col": 4 * n * n + 4 * n * n + 8 * (n // 2 + 2) * (n // 2),
+            "r2c": 8 * n * n, "c2r": 4 * (n // 2 + 2) * n + 4 * n * n}
 
 
 def cpu_baseline(n: int, frames: int):
@@ -97,7 +99,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # one process per GPU; RCCL ("nccl") carries device collectives (none on this data path: frames are
+        # sharded, nothing is exchanged), gloo carries the host-side barrier and the max-over-ranks of the timing
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl")
 
     from barc4dip_amd import _ffi, synth
 
@@ -115,8 +119,8 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if world > 1:   # host-side rendezvous (gloo): this data path has no device collective to piggy-back on
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64))
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -130,7 +134,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -178,7 +182,7 @@ def main():
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64))
         dist.destroy_process_group()
 
 
