@@ -7,6 +7,6 @@ from __future__ import annotations
 
 __version__ = "0.1.0"
 
-from . import geometry, maths, metrics, signal  # noqa: F401
+from . import geometry, maths, metrics, preprocessing, signal  # noqa: F401
 from .metrics import (distribution_moments, sharpness_stack_stats, sharpness_stats, speckle_stack_stats,  # noqa: F401
                       speckle_stats)

@@ -138,8 +138,8 @@ __global__ void __launch_bounds__(256) k_gen_real_out(const float2* __restrict__
 
 using namespace b4d;
 
-static int cgemm(const void* A, bool a_real, long long sA, int conj_a, const void* B, bool b_real, long long sB, int conj_b,
-                 float2* C, long long sC, int M, int N, int K, int batch, hipStream_t st) {
+int b4d_cgemm(const void* A, bool a_real, long long sA, int conj_a, const void* B, bool b_real, long long sB, int conj_b,
+              float2* C, long long sC, int M, int N, int K, int batch, hipStream_t st) {
     GemmArgs g{A, B, C, M, N, K, sA, sB, sC, conj_a, conj_b};
     const dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
     if (a_real && !b_real)
@@ -169,9 +169,9 @@ int make_dft_matrix(int n, float2** out) {
 static int dft2(const b4d_plan* pl, const void* X, bool x_real, int batch, int conj, float2* tmp, float2* F, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx;
     const long long fp = (long long)ny * nx;
-    int rc = cgemm(X, x_real, fp, 0, pl->wx, false, 0, conj, tmp, fp, ny, nx, nx, batch, st);
+    int rc = b4d_cgemm(X, x_real, fp, 0, pl->wx, false, 0, conj, tmp, fp, ny, nx, nx, batch, st);
     if (rc) return rc;
-    return cgemm(pl->wy, false, 0, conj, tmp, false, fp, 0, F, fp, ny, nx, ny, batch, st);
+    return b4d_cgemm(pl->wy, false, 0, conj, tmp, false, fp, 0, F, fp, ny, nx, ny, batch, st);
 }
 
 int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* psd, float psd_scale, float* autocorr,
@@ -190,8 +190,8 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
         if (!autocorr) continue;
         // inverse of the REAL power spectrum: tmp = P * conj(Wx) lands in gbuf2, result in gbuf3
         const long long fp = npix;
-        if ((rc = cgemm(P, true, fp, 0, pl->wx, false, 0, 1, pl->gbuf2, fp, ny, nx, nx, nb, st))) return rc;
-        if ((rc = cgemm(pl->wy, false, 0, 1, pl->gbuf2, false, fp, 0, pl->gbuf3, fp, ny, nx, ny, nb, st))) return rc;
+        if ((rc = b4d_cgemm(P, true, fp, 0, pl->wx, false, 0, 1, pl->gbuf2, fp, ny, nx, nx, nb, st))) return rc;
+        if ((rc = b4d_cgemm(pl->wy, false, 0, 1, pl->gbuf2, false, fp, 0, pl->gbuf3, fp, ny, nx, ny, nb, st))) return rc;
         hipLaunchKernelGGL(k_gen_real_out, dim3(eg.x, nb), dim3(256), 0, st, pl->gbuf3, ny, nx, autocorr + off,
                            1.0f / ((float)nx * (float)ny), flags);
         B4D_HIP(hipGetLastError());
@@ -222,8 +222,8 @@ int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float
         if ((rc = dft2(pl, b + off, true, nb, 0, pl->gbuf1, pl->gbuf3, st))) return rc;
         hipLaunchKernelGGL(k_gen_cross, dim3((npix + 255) / 256, nb), dim3(256), 0, st, pl->gbuf2, pl->gbuf3, npix, pl->gbuf2, flags);
         B4D_HIP(hipGetLastError());
-        if ((rc = cgemm(pl->gbuf2, false, fp, 0, pl->wx, false, 0, 1, pl->gbuf1, fp, ny, nx, nx, nb, st))) return rc;
-        if ((rc = cgemm(pl->wy, false, 0, 1, pl->gbuf1, false, fp, 0, pl->gbuf3, fp, ny, nx, ny, nb, st))) return rc;
+        if ((rc = b4d_cgemm(pl->gbuf2, false, fp, 0, pl->wx, false, 0, 1, pl->gbuf1, fp, ny, nx, nx, nb, st))) return rc;
+        if ((rc = b4d_cgemm(pl->wy, false, 0, 1, pl->gbuf1, false, fp, 0, pl->gbuf3, fp, ny, nx, ny, nb, st))) return rc;
         hipLaunchKernelGGL(k_gen_real_out, dim3((npix + 255) / 256, nb), dim3(256), 0, st, pl->gbuf3, ny, nx, corr + off,
                            1.0f / ((float)nx * (float)ny), 0u);
         B4D_HIP(hipGetLastError());

@@ -1,0 +1,343 @@
+// b4d_wiener.hip -- Gaussian-PSF Wiener deconvolution of barc4dip.preprocessing.deconvolve_psf
+// (preprocessing/filters.py:17-289, method="wiener"; BASELINE.json config 5) on gfx950.
+//
+// The reference pads every frame by psf//2 with "reflect", normalises by max|.|, applies the Wiener-Hunt
+// filter of skimage.restoration.wiener in the Fourier domain of the PADDED size, clips to [-1, 1], rescales
+// and crops.  The padded sizes are awkward by construction (4096 + 2*4 = 4104 = 2^3 * 3^3 * 19), so the
+// transforms here are mixed: N = P * M with P <= 16 a power of two done as an in-register radix-P butterfly
+// plus twiddles, and the length-M part as a dense DFT-matrix product (the complex GEMM of b4d_general.hip):
+//
+//   X[k1 + P k2] = sum_{n2 < M} W_M^{n2 k2} [ W_N^{n2 k1} sum_{n1 < P} x[M n1 + n2] W_P^{n1 k1} ]
+//
+// 2-D: row pass, transpose, row pass (the spectrum stays transposed: the filter is stored transposed as well),
+// multiply, and the same two passes back with conjugated inputs/outputs.
+// Parity: UNPINNED (scikit-image is not installable here); oracle/wiener_np.py restates the published algorithm.
+#include "b4d_fft2d.hpp"
+
+// complex GEMM of b4d_general.hip
+int b4d_cgemm(const void* A, bool a_real, long long sA, int conj_a, const void* B, bool b_real, long long sB, int conj_b,
+              float2* C, long long sC, int M, int N, int K, int batch, hipStream_t st);
+
+namespace b4d {
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+
+// step A: y[(s*P + k1)*M + n2] = W_N^{n2 k1} * sum_{n1} x[s*N + M n1 + n2] * W_P^{n1 k1}     (conj_in: x -> conj x)
+// one lane per (s, n2); twN: N-point twiddles exp(-2 pi i k / N).  grid (ceil(M/256), S)
+template <int P, bool REAL_IN>
+__global__ void __launch_bounds__(256) k_pm_pre(const void* __restrict__ xin, float2* __restrict__ y, const float2* __restrict__ twN,
+                                                int M, int conj_in) {
+    const int n2 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n2 >= M) return;
+    const size_t s = blockIdx.y;
+    const int N = P * M;
+    float2 v[P];
+#pragma unroll
+    for (int n1 = 0; n1 < P; ++n1) {
+        const size_t i = s * (size_t)N + (size_t)M * n1 + n2;
+        if (REAL_IN) {
+            v[n1] = make_float2(static_cast<const float*>(xin)[i], 0.f);
+        } else {
+            const float2 q = static_cast<const float2*>(xin)[i];
+            v[n1] = conj_in ? make_float2(q.x, -q.y) : q;
+        }
+    }
+    Dft<P>::run(v);
+#pragma unroll
+    for (int k1 = 0; k1 < P; ++k1) {
+        const float2 w = k1 == 0 ? make_float2(1.f, 0.f) : twN[(size_t)((long long)n2 * k1 % N)];
+        y[(s * P + k1) * (size_t)M + n2] = cmulf(v[k1], w);
+    }
+}
+
+// step C: out[s*N + k1 + P k2] = z[(s*P + k1)*M + k2]  (* filt[same index], conj_out, * scale).  grid (ceil(N/256), S)
+__global__ void __launch_bounds__(256) k_pm_post(const float2* __restrict__ z, float2* __restrict__ out, int P, int M,
+                                                 const float2* __restrict__ filt, int conj_out, float scale) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = P * M;
+    if (k >= N) return;
+    const size_t s = blockIdx.y;
+    const int k1 = k % P, k2 = k / P;
+    float2 v = z[(s * P + k1) * (size_t)M + k2];
+    if (filt) v = cmulf(v, filt[s * (size_t)N + k]);
+    if (conj_out) v.y = -v.y;
+    out[s * (size_t)N + k] = make_float2(v.x * scale, v.y * scale);
+}
+
+// 32 x 32 LDS-tiled transpose of a (rows, cols) complex array.  grid (ceil(cols/32), ceil(rows/32)), block (32, 8)
+__global__ void __launch_bounds__(256) k_transpose_c(const float2* __restrict__ in, float2* __restrict__ out, int rows, int cols) {
+    __shared__ float2 t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) t[i][threadIdx.x] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = t[threadIdx.x][i];
+    }
+}
+
+// np.pad(frame, ((py,py),(px,px)), mode="reflect") / scale  (filters.py:252-261); scale = max|frame| read from `amax`
+__global__ void __launch_bounds__(256) k_pad_reflect(const float* __restrict__ frame, int h, int w, int py, int px,
+                                                     const float* __restrict__ amax, int nparts, float* __restrict__ out) {
+    __shared__ float s_scale;
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int i = 0; i < nparts; ++i) m = fmaxf(m, amax[i]);
+        s_scale = m;
+    }
+    __syncthreads();
+    const int H = h + 2 * py, W = w + 2 * px;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)H * W) return;
+    int y = (int)(e / W) - py, x = (int)(e % W) - px;
+    y = y < 0 ? -y : (y >= h ? 2 * h - 2 - y : y);
+    x = x < 0 ? -x : (x >= w ? 2 * w - 2 - x : x);
+    const float sc = s_scale;
+    out[e] = (isfinite(sc) && sc != 0.f) ? frame[(size_t)y * w + x] / sc : 0.f;
+}
+
+// restored = clip(Re(z), -1, 1) * scale, cropped back to (h, w)  (filters.py:266, 287-289)
+__global__ void __launch_bounds__(256) k_crop_out(const float2* __restrict__ z, int h, int w, int py, int px,
+                                                  const float* __restrict__ amax, int nparts, int clip, float* __restrict__ out) {
+    __shared__ float s_scale;
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int i = 0; i < nparts; ++i) m = fmaxf(m, amax[i]);
+        s_scale = m;
+    }
+    __syncthreads();
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)h * w) return;
+    const int y = (int)(e / w), x = (int)(e % w), W = w + 2 * px;
+    float v = z[(size_t)(y + py) * W + x + px].x;
+    if (clip) v = fminf(fmaxf(v, -1.f), 1.f);
+    const float sc = s_scale;
+    out[e] = (isfinite(sc) && sc != 0.f) ? v * sc : 0.f;
+}
+
+// max|x| partials, NaN-ignoring (np.nanmax(np.abs(padded)))
+__global__ void __launch_bounds__(1024) k_nanabsmax(const float* __restrict__ x, size_t n, float* __restrict__ part) {
+    __shared__ float sh[16];
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = fabsf(x[i]);
+        if (a == a) m = fmaxf(m, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, sh[i]);
+        part[blockIdx.x] = m;
+    }
+}
+
+// W^T = conj(H) / (|H|^2 + balance |L|^2) from the (transposed) transfer functions of the PSF and the Laplacian
+__global__ void __launch_bounds__(256) k_wiener_filter(const float2* __restrict__ Hf, const float2* __restrict__ Lf, size_t n,
+                                                       float balance, float2* __restrict__ Wf) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float2 h = Hf[e], l = Lf[e];
+    const float den = (h.x * h.x + h.y * h.y) + balance * (l.x * l.x + l.y * l.y);
+    Wf[e] = make_float2(h.x / den, -h.y / den);
+}
+
+}  // namespace b4d
+
+using namespace b4d;
+
+struct b4d_wiener {
+    int h, w, py, px, H, W;      // frame, half kernel, padded sizes
+    int Px, Mx, Py, My;          // H = Py*My, W = Px*Mx
+    float2* twx = nullptr;       // W-point twiddles
+    float2* twy = nullptr;
+    float2* dmx = nullptr;       // Mx x Mx DFT matrix
+    float2* dmy = nullptr;
+    float2* filt = nullptr;      // transposed Wiener filter (W, H)
+    float2* a = nullptr;         // (H*W) work buffers
+    float2* b = nullptr;
+    float2* c = nullptr;
+    float* padded = nullptr;     // (H, W) real
+    float* amax = nullptr;       // 256 partial maxima
+};
+
+static void split_pm(int n, int* P, int* M) {
+    int p = 1;
+    while (p < 16 && n % (2 * p) == 0) p *= 2;
+    *P = p;
+    *M = n / p;
+}
+
+template <int P>
+static int pm_pre_launch(const void* x, bool real_in, float2* y, const float2* tw, int M, int S, int conj_in, hipStream_t st) {
+    const dim3 grid((M + 255) / 256, S);
+    if (real_in)
+        hipLaunchKernelGGL((k_pm_pre<P, true>), grid, dim3(256), 0, st, x, y, tw, M, conj_in);
+    else
+        hipLaunchKernelGGL((k_pm_pre<P, false>), grid, dim3(256), 0, st, x, y, tw, M, conj_in);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+// S sequences of length N = P*M, contiguous: out = DFT(in) (forward) or conj(DFT(conj(in))) * scale (inverse);
+// tmp holds S*N complex values; optional pointwise multiplier applied to the forward output.
+static int dft_rows(const void* in, bool real_in, float2* tmp, float2* tmp2, float2* out, int S, int P, int M, const float2* tw,
+                    const float2* dm, bool inverse, const float2* filt, float scale, hipStream_t st) {
+    int rc;
+    switch (P) {
+        case 1: rc = pm_pre_launch<1>(in, real_in, tmp, tw, M, S, inverse, st); break;
+        case 2: rc = pm_pre_launch<2>(in, real_in, tmp, tw, M, S, inverse, st); break;
+        case 4: rc = pm_pre_launch<4>(in, real_in, tmp, tw, M, S, inverse, st); break;
+        case 8: rc = pm_pre_launch<8>(in, real_in, tmp, tw, M, S, inverse, st); break;
+        case 16: rc = pm_pre_launch<16>(in, real_in, tmp, tw, M, S, inverse, st); break;
+        default: return fail(B4D_ESIZE, "unsupported radix");
+    }
+    if (rc) return rc;
+    // (S*P, M) x (M, M); rows are independent, so slice the batch to keep the launch grid.y within limits
+    const long long rows = (long long)S * P;
+    if ((rc = b4d_cgemm(tmp, false, 0, 0, dm, false, 0, 0, tmp2, 0, (int)rows, M, M, 1, st))) return rc;
+    hipLaunchKernelGGL(k_pm_post, dim3((P * M + 255) / 256, S), dim3(256), 0, st, tmp2, out, P, M, filt, inverse ? 1 : 0, scale);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+static int transpose_c(const float2* in, float2* out, int rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(k_transpose_c, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, in, out, rows, cols);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+// forward 2-D DFT of a real (H, W) array -> TRANSPOSED spectrum (W, H), left in pl->a (b, c are scratch).
+// dft_rows needs in != tmp != tmp2 != out (its first and last steps are permutations).
+static int fft2_real_T(b4d_wiener* pl, const float* x, hipStream_t st) {
+    int rc = dft_rows(x, true, pl->a, pl->b, pl->c, pl->H, pl->Px, pl->Mx, pl->twx, pl->dmx, false, nullptr, 1.f, st);
+    if (rc) return rc;
+    if ((rc = transpose_c(pl->c, pl->a, pl->H, pl->W, st))) return rc;
+    return dft_rows(pl->a, false, pl->b, pl->c, pl->a, pl->W, pl->Py, pl->My, pl->twy, pl->dmy, false, nullptr, 1.f, st);
+}
+
+extern "C" {
+
+int b4d_wiener_destroy(b4d_wiener* p) {
+    if (!p) return B4D_OK;
+    for (void* q : {(void*)p->twx, (void*)p->twy, (void*)p->dmx, (void*)p->dmy, (void*)p->filt, (void*)p->a, (void*)p->b, (void*)p->c,
+                    (void*)p->padded, (void*)p->amax})
+        if (q) (void)hipFree(q);
+    delete p;
+    return B4D_OK;
+}
+
+int b4d_wiener_create(int h, int w, const float* psf_host, int ky, int kx, float balance, b4d_wiener** out) {
+    if (!out || !psf_host) return fail(B4D_EINVAL, "null argument");
+    *out = nullptr;
+    if (h < 2 || w < 2 || ky < 1 || kx < 1 || !(ky & 1) || !(kx & 1)) return fail(B4D_EINVAL, "bad frame or kernel shape");
+    if (ky / 2 >= h || kx / 2 >= w) return fail(B4D_EINVAL, "kernel larger than the frame");
+    b4d_wiener* p = new b4d_wiener();
+    p->h = h;
+    p->w = w;
+    p->py = ky / 2;
+    p->px = kx / 2;
+    p->H = h + 2 * p->py;
+    p->W = w + 2 * p->px;
+    split_pm(p->W, &p->Px, &p->Mx);
+    split_pm(p->H, &p->Py, &p->My);
+    if (p->Mx > 4200 || p->My > 4200) {
+        b4d_wiener_destroy(p);
+        return fail(B4D_ESIZE, "padded size " + std::to_string(p->H) + "x" + std::to_string(p->W) + " has an odd factor > 4200");
+    }
+    int rc = make_twiddles(p->W, &p->twx);
+    if (rc == B4D_OK) rc = make_twiddles(p->H, &p->twy);
+    if (rc == B4D_OK) rc = make_dft_matrix(p->Mx, &p->dmx);
+    if (rc == B4D_OK) rc = make_dft_matrix(p->My, &p->dmy);
+    const size_t n = (size_t)p->H * p->W;
+    hipError_t e = hipSuccess;
+    if (rc == B4D_OK) {
+        e = hipMalloc((void**)&p->filt, sizeof(float2) * n);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->a, sizeof(float2) * n);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->b, sizeof(float2) * n);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->c, sizeof(float2) * n);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->padded, sizeof(float) * n);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->amax, sizeof(float) * 256);
+        if (e != hipSuccess) rc = fail(B4D_ENOMEM, std::string("wiener workspace: ") + hipGetErrorString(e));
+    }
+    if (rc != B4D_OK) {
+        b4d_wiener_destroy(p);
+        return rc;
+    }
+    // transfer functions (published skimage.restoration.uft.ir2tf): kernel in the top-left corner of a zero (H, W)
+    // array, every axis rolled by -floor(size/2), 2-D DFT.  Built on the host, transformed on the device.
+    auto impulse = [&](const float* k, int kh, int kw, std::vector<float>& img) {
+        img.assign(n, 0.f);
+        for (int i = 0; i < kh; ++i)
+            for (int j = 0; j < kw; ++j) {
+                const int y = ((i - kh / 2) % p->H + p->H) % p->H, x = ((j - kw / 2) % p->W + p->W) % p->W;
+                img[(size_t)y * p->W + x] = k[i * kw + j];
+            }
+    };
+    std::vector<float> img;
+    float2* Hf = nullptr;
+    e = hipMalloc((void**)&Hf, sizeof(float2) * n);
+    if (e != hipSuccess) {
+        b4d_wiener_destroy(p);
+        return fail(B4D_ENOMEM, "wiener setup allocation");
+    }
+    hipStream_t st = nullptr;
+    impulse(psf_host, ky, kx, img);
+    rc = (hipMemcpy(p->padded, img.data(), sizeof(float) * n, hipMemcpyHostToDevice) == hipSuccess) ? B4D_OK : fail(B4D_EHIP, "memcpy");
+    if (rc == B4D_OK) rc = fft2_real_T(p, p->padded, st);
+    if (rc == B4D_OK && hipMemcpyAsync(Hf, p->a, sizeof(float2) * n, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        rc = fail(B4D_EHIP, "memcpy");
+    const float lap[9] = {0.f, -1.f, 0.f, -1.f, 4.f, -1.f, 0.f, -1.f, 0.f};
+    if (rc == B4D_OK) {
+        impulse(lap, 3, 3, img);
+        rc = (hipMemcpy(p->padded, img.data(), sizeof(float) * n, hipMemcpyHostToDevice) == hipSuccess) ? B4D_OK : fail(B4D_EHIP, "memcpy");
+    }
+    if (rc == B4D_OK) rc = fft2_real_T(p, p->padded, st);  // Laplacian transfer function in p->a
+    if (rc == B4D_OK) {
+        hipLaunchKernelGGL(k_wiener_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Hf, p->a, n, balance, p->filt);
+        if (hipDeviceSynchronize() != hipSuccess) rc = fail(B4D_EHIP, "wiener filter setup failed");
+    }
+    (void)hipFree(Hf);
+    if (rc != B4D_OK) {
+        b4d_wiener_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return B4D_OK;
+}
+
+int b4d_wiener_apply(b4d_wiener* p, const float* frames, int batch, float* out, int clip, void* stream) {
+    if (!p || !frames || !out) return fail(B4D_EINVAL, "null argument");
+    if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t fp = (size_t)p->h * p->w, n = (size_t)p->H * p->W;
+    const float inv = 1.0f / (float)n;
+    for (int b = 0; b < batch; ++b) {
+        const float* f = frames + b * fp;
+        hipLaunchKernelGGL(k_nanabsmax, dim3(256), dim3(1024), 0, st, f, fp, p->amax);
+        hipLaunchKernelGGL(k_pad_reflect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, p->h, p->w, p->py, p->px, p->amax, 256,
+                           p->padded);
+        B4D_HIP(hipGetLastError());
+        // forward: rows (padded -> c), transpose (c -> a), columns + filter (a -> a), all in the transposed domain after that
+        int rc = dft_rows(p->padded, true, p->a, p->b, p->c, p->H, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st);
+        if (rc) return rc;
+        if ((rc = transpose_c(p->c, p->a, p->H, p->W, st))) return rc;
+        if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, p->W, p->Py, p->My, p->twy, p->dmy, false, p->filt, 1.f, st))) return rc;
+        // inverse: columns (a -> a), transpose (a -> b), rows (b -> b) with the 1/(H W) factor
+        if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, p->W, p->Py, p->My, p->twy, p->dmy, true, nullptr, 1.f, st))) return rc;
+        if ((rc = transpose_c(p->a, p->b, p->W, p->H, st))) return rc;
+        if ((rc = dft_rows(p->b, false, p->c, p->a, p->b, p->H, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st))) return rc;
+        hipLaunchKernelGGL(k_crop_out, dim3((unsigned)((fp + 255) / 256)), dim3(256), 0, st, p->b, p->h, p->w, p->py, p->px, p->amax, 256,
+                           clip, out + b * fp);
+        B4D_HIP(hipGetLastError());
+    }
+    return B4D_OK;
+}
+
+}  // extern "C"

@@ -135,6 +135,17 @@ int b4d_radial_profile(const float* maps, int batch, int ny, int nx, int nr, int
  * sum P^2 (all four over the inscribed frequency disc), S_all, sum P ln P (all bins), f95 (square maps)}.  */
 int b4d_psd_stats(const float* psd, int batch, int ny, int nx, double* out, void* stream);
 
+/* preprocessing/filters.py:17-289 deconvolve_psf, method="wiener" (BASELINE.json config 5).
+ * create: frame shape (h, w), PSF (ky, kx odd; HOST pointer, row-major float32, filters.py:217-230), Wiener-Hunt
+ *   regularisation `balance` (skimage.restoration.wiener, Laplacian regulariser).  The padded size (h + 2*(ky/2),
+ *   w + 2*(kx/2)) may be any integer whose odd part is <= 4200 (4096 + 8 = 4104 = 8 * 513 for sigma 1.5).
+ * apply: per frame reflect-pad, divide by max|.|, filter in the Fourier domain of the padded size, clip to [-1, 1]
+ *   (if clip), rescale, crop -> out (batch, h, w) float32.                                                      */
+typedef struct b4d_wiener b4d_wiener;
+int b4d_wiener_create(int h, int w, const float* psf, int ky, int kx, float balance, b4d_wiener** out);
+int b4d_wiener_apply(b4d_wiener* plan, const float* frames, int batch, float* out, int clip, void* stream);
+int b4d_wiener_destroy(b4d_wiener* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,52 @@
+"""GPU tier: deconvolve_psf (Wiener) through the C ABI vs the (unpinned) oracle restatement.
+Tolerance: float32 transforms on both sides, compared normwise at 2e-5 of the frame maximum."""
+import numpy as np
+import pytest
+
+from barc4dip_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pp():
+    import torch
+
+    assert torch.cuda.is_available()
+    from barc4dip_amd import preprocessing
+
+    return preprocessing
+
+
+@pytest.mark.parametrize("shape,sigma", [((60, 52), 1.5), ((64, 64), (1.0, 2.0)), ((100, 37), 0.7), ((512, 512), 1.5)])
+@pytest.mark.parametrize("clip", [True, False])
+def test_wiener_vs_oracle(pp, shape, sigma, clip):
+    from oracle import wiener_np as W
+
+    img = synth.speckle_frame(512, 9)[:shape[0], :shape[1]].copy()
+    got = pp.deconvolve_psf(img, sigma=sigma, clip=clip)
+    ref = W.deconvolve_psf(img, sigma=sigma, clip=clip)
+    assert got.shape == img.shape and got.dtype == np.float32
+    assert float(np.max(np.abs(got - ref))) < 2e-5 * float(np.max(np.abs(img)))
+
+
+def test_stack_balance_and_errors(pp):
+    from oracle import wiener_np as W
+
+    stack = synth.speckle_stack(3, 128, seed0=40)[:, :100, :120].copy()
+    got = pp.deconvolve_psf(stack, sigma=1.5, balance=0.1)
+    ref = W.deconvolve_psf(stack, sigma=1.5, balance=0.1)
+    assert float(np.max(np.abs(got - ref))) < 2e-5 * float(stack.max())
+    assert np.all(pp.deconvolve_psf(np.zeros((32, 32), np.float32), sigma=1.0) == 0)
+    with pytest.raises(TypeError):
+        pp.deconvolve_psf([[1.0]], sigma=1.0)
+    with pytest.raises(ValueError):
+        pp.deconvolve_psf(stack[0, 0], sigma=1.0)
+    with pytest.raises(ValueError):
+        pp.deconvolve_psf(stack, sigma=-1.0)
+    with pytest.raises(ValueError):
+        pp.deconvolve_psf(stack, sigma=1.0, method="bogus")
+    with pytest.raises(ValueError):
+        pp.deconvolve_psf(stack, sigma=1.0, pad_mode="edge")
+    with pytest.raises(NotImplementedError):
+        pp.deconvolve_psf(stack, sigma=1.0, method="rl")
