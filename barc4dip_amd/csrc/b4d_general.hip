@@ -85,6 +85,63 @@ __global__ void __launch_bounds__(256) k_cgemm(GemmArgs g) {
     }
 }
 
+// The same product on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate, bit-for-bit an fmaf chain).
+// 64 x 64 complex tile per workgroup, 4 waves in 2 x 2, each wave a 32 x 32 complex tile = two f32x16 accumulators
+// (re, im); per k-step of 2 one ds_read_b64 per operand feeds four MFMAs:
+//   Cr += Ar*Br - Ai*Bi,  Ci += Ar*Bi + Ai*Br.
+// Fragment maps (MI355X guide §3): A: lane l holds A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31];
+// C/D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool AREAL, bool BREAL>
+__global__ void __launch_bounds__(256) k_cgemm_mfma(GemmArgs g) {
+    __shared__ float2 As[16][65];  // [k][m]
+    __shared__ float2 Bs[16][65];  // [k][n]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const long long oa = (long long)blockIdx.z * g.sA, ob = (long long)blockIdx.z * g.sB, oc = (long long)blockIdx.z * g.sC;
+    f32x16 cr, ci;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cr[r] = ci[r] = 0.f;
+    const int li = lane & 31, lk = lane >> 5;
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = threadIdx.x + 256 * r;
+            {
+                const int kk = e & 15, mm = e >> 4;
+                const int m = m0 + mm, k = k0 + kk;
+                As[kk][mm] = (m < g.M && k < g.K) ? ld_elem<AREAL>(g.A, oa + (long long)m * g.K + k, g.conj_a) : make_float2(0.f, 0.f);
+            }
+            {
+                const int nn = e & 63, kk = e >> 6;
+                const int n = n0 + nn, k = k0 + kk;
+                Bs[kk][nn] = (n < g.N && k < g.K) ? ld_elem<BREAL>(g.B, ob + (long long)k * g.N + n, g.conj_b) : make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float2 a = As[kk + lk][32 * wr + li];
+            const float2 b = Bs[kk + lk][32 * wc + li];
+            cr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, cr, 0, 0, 0);
+            cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.y, b.y, cr, 0, 0, 0);
+            ci = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, ci, 0, 0, 0);
+            ci = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, ci, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + 32 * wc + li;
+    if (n < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < g.M) g.C[oc + (long long)m * g.N + n] = make_float2(cr[r], ci[r]);
+        }
+    }
+}
+
 // ---- elementwise epilogues (one lane per pixel; grid (ceil(npix/256), batch))
 __global__ void __launch_bounds__(256) k_gen_power(const float2* __restrict__ F, int ny, int nx, float* __restrict__ psd,
                                                    float scale, float* __restrict__ P, unsigned flags) {
@@ -142,10 +199,17 @@ int b4d_cgemm(const void* A, bool a_real, long long sA, int conj_a, const void* 
               float2* C, long long sC, int M, int N, int K, int batch, hipStream_t st) {
     GemmArgs g{A, B, C, M, N, K, sA, sB, sC, conj_a, conj_b};
     const dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+#ifdef B4D_CGEMM_VALU   // reference build: the vector-ALU product (tools/dev_ab.py compares both)
     if (a_real && !b_real)
         hipLaunchKernelGGL((k_cgemm<true, false>), grid, dim3(256), 0, st, g);
     else if (!a_real && !b_real)
         hipLaunchKernelGGL((k_cgemm<false, false>), grid, dim3(256), 0, st, g);
+#else
+    if (a_real && !b_real)
+        hipLaunchKernelGGL((k_cgemm_mfma<true, false>), grid, dim3(256), 0, st, g);
+    else if (!a_real && !b_real)
+        hipLaunchKernelGGL((k_cgemm_mfma<false, false>), grid, dim3(256), 0, st, g);
+#endif
     else
         return fail(B4D_EINVAL, "cgemm: unsupported operand types");
     B4D_HIP(hipGetLastError());

@@ -80,6 +80,22 @@ class _WienerPlan:
             pass
 
 
+_wiener_plans: dict = {}
+
+
+def _wiener_plan(h, w, psf, balance) -> _WienerPlan:
+    """Plans (DFT matrices, transposed filter, work buffers) are cached per (shape, PSF, balance, device)."""
+    import torch
+
+    key = (int(h), int(w), psf.shape, psf.tobytes(), float(balance), torch.cuda.current_device())
+    pl = _wiener_plans.get(key)
+    if pl is None:
+        if len(_wiener_plans) >= 4:
+            _wiener_plans.pop(next(iter(_wiener_plans)))
+        pl = _wiener_plans[key] = _WienerPlan(h, w, psf, balance)
+    return pl
+
+
 def deconvolve_psf(images: np.ndarray, *, sigma: float | Sequence[float], method: _DeconvMethod = "wiener", clip: bool = True,
                    pad_mode: Literal["reflect"] = "reflect", balance: float | None = None, num_iter: int = 50,
                    filter_epsilon: float | None = None, reg: float | None = None, user_params: dict | None = None,
@@ -103,7 +119,7 @@ def deconvolve_psf(images: np.ndarray, *, sigma: float | Sequence[float], method
         balance = 0.01
     stack = images if images.ndim == 3 else images[None]
     dev, _, _ = D.to_device_f32(stack, ndim=(3,))
-    plan = _WienerPlan(dev.shape[1], dev.shape[2], psf, balance)
+    plan = _wiener_plan(dev.shape[1], dev.shape[2], psf, balance)
     out = plan.apply(dev, clip)
     if images.ndim == 2:
         out = out[0]
