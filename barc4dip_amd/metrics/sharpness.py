@@ -154,13 +154,39 @@ def eigenvalues(image, *, k: int = 5, eps: float = 1e-30, verbose: bool = False)
     return out
 
 
+def _eig_from_svals(s2_over_denom: np.ndarray, k: int, eps: float) -> dict:
+    eig = s2_over_denom
+    e1 = float(eig[0]) if eig.size >= 1 else 0.0
+    e2 = float(eig[1]) if eig.size >= 2 else 0.0
+    return {"eigenvalues": float(np.sum(eig[:min(int(k), int(eig.size))])), "e1": e1, "e2": e2, "re": float(e1 / (e2 + float(eps)))}
+
+
+def _eigenvalues_batch(stack, k: int = 5, eps: float = 1e-30) -> list[dict]:
+    """STA2 eigenvalues of a (B, h, w) device stack in one batched device SVD call."""
+    import torch
+
+    x = stack.double()
+    energy = torch.sqrt((x * x).sum(dim=(1, 2), keepdim=True))
+    j = x / energy
+    j = j - j.mean(dim=(1, 2), keepdim=True)
+    denom = float(j[0].numel() - 1)
+    s = torch.linalg.svdvals(j)
+    eig = ((s * s) / denom).cpu().numpy()
+    return [_eig_from_svals(e, k, eps) for e in eig]
+
+
 def _tiles_pointwise(t, tile_mode, groups, saturation_value, eps):
     n, batches = _tile_batches(t, tile_mode)
-    st = grad = lap = None
+    st = grad = lap = eigs = None
     for _, rcs, stack in batches:
         mom = K.moments_batch(_pad4(stack), eps=eps, saturation=saturation_value).cpu().numpy() if "stats" in groups else None
         sl = K.sobel_laplace_batch(stack).cpu().numpy() if groups & {"gradient", "laplacian"} else None
+        ev = _eigenvalues_batch(stack) if "eigenvalues" in groups else None
         for i, (r, c) in enumerate(rcs):
+            if ev is not None:
+                eigs = eigs or {k: np.empty((n, n)) for k in ev[i]}
+                for k in eigs:
+                    eigs[k][r, c] = ev[i][k]
             if mom is not None:
                 d = moments_from_sums(mom[i], saturation_value)
                 st = st or {k: np.empty((n, n)) for k in d}
@@ -181,6 +207,8 @@ def _tiles_pointwise(t, tile_mode, groups, saturation_value, eps):
         out["gradient"] = grids_to_fields(grad, n)
     if lap is not None:
         out["laplacian"] = grids_to_fields(lap, n)
+    if eigs is not None:
+        out["eigenvalues"] = grids_to_fields(eigs, n)
     return out
 
 
@@ -218,8 +246,6 @@ def sharpness_stats(image: np.ndarray, *, metrics: str | Sequence[str] = "all", 
         return out
     out["meta"].update(tiles_meta(h, w, tile_mode=mode, tile_shape_px=tile_shape_px))
     tiles_out = _tiles_pointwise(t, mode, groups, saturation_value, eps)
-    if "eigenvalues" in groups:
-        tiles_out["eigenvalues"] = tiled_scalar_fields(t, tile_mode=mode, compute_fn=eigenvalues)
     fft_groups = sorted(groups & _FFT_GROUPS)
     if fft_groups:
         n, ys, xs = tile_spans(h, w, mode)
