@@ -127,52 +127,69 @@ def inverse_autocorr_width(image, *, fraction: float = 1.0 / np.e,
     return out
 
 
-def eigenvalues(image, *, k: int = 5, eps: float = 1e-30, verbose: bool = False) -> dict:
-    """STA2: eig = s^2/(M*N-1) of the energy-normalised, mean-removed image; sum of the first k, e1, e2, e1/e2
-    (reference: sharpness.py:752-861)."""
-    import torch
+def _sta2_device(stack, nout: int = 8) -> np.ndarray:
+    """Leading STA2 eigenvalues of a (B, h, w) float32 device stack: (B, nout) float64, descending (b4d_sta2_eigenvalues)."""
+    import ctypes as C
 
-    t = _check2d(image, "eigenvalues", all_finite=True)
-    if int(k) < 1:
-        raise ValueError("k must be >= 1.")
-    x = t.double()
-    energy = float(torch.sqrt((x * x).sum()))
-    if not np.isfinite(energy) or energy <= 0.0:
-        raise ValueError("eigenvalues cannot normalize an all-zero image.")
-    j = x / energy
-    j = j - j.mean()
-    denom = float(j.numel() - 1)
-    if denom <= 0.0:
-        raise ValueError("eigenvalues requires at least 2 pixels (M*N >= 2).")
-    s = torch.linalg.svdvals(j)
-    eig = ((s * s) / denom).cpu().numpy()
-    e1 = float(eig[0]) if eig.size >= 1 else 0.0
-    e2 = float(eig[1]) if eig.size >= 2 else 0.0
-    out = {"eigenvalues": float(np.sum(eig[:min(int(k), int(eig.size))])), "e1": e1, "e2": e2, "re": float(e1 / (e2 + float(eps)))}
-    if verbose:
-        logger.info("> eigenvalues: %.6g | e1: %.6g | e2: %.6g | e1/e2: %.3f", out["eigenvalues"], e1, e2, out["re"])
+    from .. import _ffi
+
+    b, h, w = (int(v) for v in stack.shape)
+    out = np.empty((b, nout), dtype=np.float64)
+    _ffi.check(_ffi.lib().b4d_sta2_eigenvalues(C.c_void_p(stack.data_ptr()), b, h, w, out.ctypes.data_as(C.c_void_p), nout,
+                                                _ffi.stream_ptr()))
     return out
 
 
-def _eig_from_svals(s2_over_denom: np.ndarray, k: int, eps: float) -> dict:
-    eig = s2_over_denom
-    e1 = float(eig[0]) if eig.size >= 1 else 0.0
-    e2 = float(eig[1]) if eig.size >= 2 else 0.0
-    return {"eigenvalues": float(np.sum(eig[:min(int(k), int(eig.size))])), "e1": e1, "e2": e2, "re": float(e1 / (e2 + float(eps)))}
+_STA2_MIN_SIDE = 64     # below this the 32-vector subspace is most of the matrix: dense device SVD instead
+_STA2_MAX_K = 8
 
 
-def _eigenvalues_batch(stack, k: int = 5, eps: float = 1e-30) -> list[dict]:
-    """STA2 eigenvalues of a (B, h, w) device stack in one batched device SVD call."""
+def _sta2_svd(stack) -> np.ndarray:
+    """Every eigenvalue of small / wide-k cases from a batched device SVD (rocSOLVER through torch)."""
     import torch
 
     x = stack.double()
     energy = torch.sqrt((x * x).sum(dim=(1, 2), keepdim=True))
     j = x / energy
     j = j - j.mean(dim=(1, 2), keepdim=True)
-    denom = float(j[0].numel() - 1)
     s = torch.linalg.svdvals(j)
-    eig = ((s * s) / denom).cpu().numpy()
+    return ((s * s) / float(j[0].numel() - 1)).cpu().numpy()
+
+
+def _eig_from_svals(eig: np.ndarray, k: int, eps: float) -> dict:
+    e1 = float(eig[0]) if eig.size >= 1 else 0.0
+    e2 = float(eig[1]) if eig.size >= 2 else 0.0
+    return {"eigenvalues": float(np.sum(eig[:min(int(k), int(eig.size))])), "e1": e1, "e2": e2, "re": float(e1 / (e2 + float(eps)))}
+
+
+def _eigenvalues_batch(stack, k: int = 5, eps: float = 1e-30) -> list[dict]:
+    """STA2 eigenvalues of a (B, h, w) float32 device stack, all frames in one call."""
+    h, w = int(stack.shape[-2]), int(stack.shape[-1])
+    if min(h, w) >= _STA2_MIN_SIDE and int(k) <= _STA2_MAX_K:
+        eig = _sta2_device(stack.contiguous())
+    else:
+        eig = _sta2_svd(stack)
     return [_eig_from_svals(e, k, eps) for e in eig]
+
+
+def eigenvalues(image, *, k: int = 5, eps: float = 1e-30, verbose: bool = False) -> dict:
+    """STA2: eig = s^2/(M*N-1) of the energy-normalised, mean-removed image; sum of the first k, e1, e2, e1/e2
+    (reference: sharpness.py:752-861).  The leading eigenvalues come from b4d_sta2_eigenvalues (Gram matrix on the
+    matrix cores + block subspace iteration); images under 64 pixels a side or k > 8 take a dense device SVD."""
+    import torch
+
+    t = _check2d(image, "eigenvalues", all_finite=True)
+    if int(k) < 1:
+        raise ValueError("k must be >= 1.")
+    energy = float(torch.sqrt((t.double() ** 2).sum()))
+    if not np.isfinite(energy) or energy <= 0.0:
+        raise ValueError("eigenvalues cannot normalize an all-zero image.")
+    if t.numel() - 1 <= 0:
+        raise ValueError("eigenvalues requires at least 2 pixels (M*N >= 2).")
+    out = _eigenvalues_batch(t.float().unsqueeze(0), k, eps)[0]
+    if verbose:
+        logger.info("> eigenvalues: %.6g | e1: %.6g | e2: %.6g | e1/e2: %.3f", out["eigenvalues"], out["e1"], out["e2"], out["re"])
+    return out
 
 
 def _tiles_pointwise(t, tile_mode, groups, saturation_value, eps):

@@ -119,6 +119,14 @@ int b4d_moments(const float* frames, int batch, size_t npix, double eps, double 
  * out: (batch, 4) float64 {mean(gx^2), mean(gy^2), mean(lap), mean(lap^2)} over finite pixels. */
 int b4d_sobel_laplace_stats(const float* frames, int batch, int ny, int nx, double* out, void* stream);
 
+/* metrics/sharpness.py:752-861 eigenvalues (STA2): J = (x - mean(x)) / ||x||_2, eig_i = s_i(J)^2 / (M N - 1).
+ * The reference takes every singular value from LAPACK and uses the first k (default 5); this returns the leading
+ * nout (<= 8) of them, descending, from the Gram matrix of the smaller side (MFMA) and a 32-vector block subspace
+ * iteration with float64 Cholesky-QR / Rayleigh-Ritz.  min(ny, nx) >= 64 required (B4D_ESIZE otherwise).
+ * frames: DEVICE (batch, ny, nx) float32.  out: HOST (batch, nout) float64; NaN rows for frames holding non-finite
+ * pixels or no energy.  Synchronises the stream.                                                                  */
+int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int nx, double* out, int nout, void* stream);
+
 /* utils/range.py:44-54 percentile_minmax_range / np.nanpercentile (linear interpolation): exact selection
  * of the two bracketing order statistics of the non-NaN pixels of every frame.  q: HOST array of nq (<= 16)
  * percentiles in [0, 100].  out: DEVICE (batch, nq, 4) float64 {x_lo, x_hi, fraction, n_valid}; the caller

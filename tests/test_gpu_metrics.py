@@ -162,3 +162,30 @@ def test_stack_stats_vs_reference_golden(gm, golden):
     np.testing.assert_allclose(got["temporal"]["abs"]["dy"], sh2[:, 0], atol=0.2)
     np.testing.assert_allclose(got["full"]["amplitude"]["visibility"], ref["full"]["amplitude"]["visibility"], rtol=1e-9)
     np.testing.assert_allclose(got["tiles"]["stats"]["mean"]["mean"], ref["tiles"]["stats"]["mean"]["mean"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("shape", [(1, 512, 512), (2, 300, 520), (2, 520, 300), (5, 228, 228), (1, 64, 64), (1, 1024, 2048)])
+def test_sta2_eigenvalues_vs_oracle(gm, shape):
+    """b4d_sta2_eigenvalues (Gram on MFMA + block subspace iteration) against the oracle's dense SVD
+    (metrics/sharpness.py:752-861).  Tolerance 1e-5 relative on the k = 5 sum, e1, e2 (float32 Gram matrix)."""
+    import torch
+
+    from barc4dip_amd import synth
+    from barc4dip_amd.metrics import sharpness as SH
+    from oracle import metrics_np as M
+
+    b, h, w = shape
+    frames = np.stack([synth.speckle_frame(max(h, w), 900 + i)[:h, :w] for i in range(b)]).astype(np.float32)
+    got = SH._eigenvalues_batch(torch.from_numpy(frames).cuda())
+    for i in range(b):
+        want = M.eigenvalues(frames[i])
+        for key in ("eigenvalues", "e1", "e2"):
+            assert got[i][key] == pytest.approx(want[key], rel=1e-5), (shape, i, key)
+        assert got[i]["re"] == pytest.approx(want["re"], rel=2e-5)
+    # low-rank image: rank 3 < subspace width, eigenvalues beyond the rank are ~0
+    rng = np.random.default_rng(3)
+    lr = (rng.random((h, 3)) @ rng.random((3, w))).astype(np.float32)
+    g = SH._eigenvalues_batch(torch.from_numpy(lr[None]).cuda(), k=5)[0]
+    wv = M.eigenvalues(lr)
+    assert g["eigenvalues"] == pytest.approx(wv["eigenvalues"], rel=1e-5)
+    assert g["e1"] == pytest.approx(wv["e1"], rel=1e-5)
