@@ -19,11 +19,49 @@
 
 namespace b4d {
 
+// Complex arithmetic on the packed-FP32 pipe (v_pk_add/mul/fma_f32: both halves of a complex value per instruction,
+// the quarter-turn and the cross terms of a product ride the op_sel / neg modifiers).  The butterflies are VALU-issue
+// bound at 4 waves per SIMD (SQ_ACTIVE_INST_VALU, profiles/): this halves their instruction count.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f to_v(float2 a) { return v2f{a.x, a.y}; }
+__device__ __forceinline__ float2 to_f(v2f a) { return make_float2(a.x, a.y); }
+
+#ifndef B4D_NO_PK
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {  // (a.x b.x - a.y b.y, a.y b.x + a.x b.y)
+    v2f t, r, x = to_v(a), y = to_v(b);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(y));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(y), "v"(t));
+    return to_f(r);
+}
+// product with a compile-time constant (cr, ci): the compiler folds the constants into scalar register pairs
+__device__ __forceinline__ float2 cmulc(float2 a, float cr, float ci) {
+    v2f x = to_v(a);
+    v2f t = x * v2f{cr, cr};
+    return to_f(__builtin_elementwise_fma(x.yx, v2f{-ci, ci}, t));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return to_f(to_v(a) + to_v(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return to_f(to_v(a) - to_v(b)); }
+// a + (-i) b  and  a - (-i) b
+__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) {
+    v2f r, x = to_v(a), y = to_v(b);
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+    return to_f(r);
+}
+__device__ __forceinline__ float2 csub_mi(float2 a, float2 b) {
+    v2f r, x = to_v(a), y = to_v(b);
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+    return to_f(r);
+}
+#else
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
+__device__ __forceinline__ float2 cmulc(float2 a, float cr, float ci) { return cmul(a, make_float2(cr, ci)); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) { return make_float2(a.x + b.y, a.y - b.x); }
+__device__ __forceinline__ float2 csub_mi(float2 a, float2 b) { return make_float2(a.x - b.y, a.y + b.x); }
+#endif
 __device__ __forceinline__ float2 cswap(float2 a) { return make_float2(a.y, a.x); }
 // multiply by -i (forward-direction quarter turn)
 __device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }
@@ -58,11 +96,20 @@ template <>
 struct Dft<4> {
     static __device__ __forceinline__ void run(float2 (&x)[4]) {
         float2 t0 = cadd(x[0], x[2]), t1 = csub(x[0], x[2]);
-        float2 t2 = cadd(x[1], x[3]), t3 = cmul_mi(csub(x[1], x[3]));
+        float2 t2 = cadd(x[1], x[3]), d = csub(x[1], x[3]);
         x[0] = cadd(t0, t2);
         x[2] = csub(t0, t2);
-        x[1] = cadd(t1, t3);
-        x[3] = csub(t1, t3);
+        x[1] = cadd_mi(t1, d);
+        x[3] = csub_mi(t1, d);
+    }
+    // same with a pending factor -i on x[2]
+    static __device__ __forceinline__ void run_mi2(float2 (&x)[4]) {
+        float2 t0 = cadd_mi(x[0], x[2]), t1 = csub_mi(x[0], x[2]);
+        float2 t2 = cadd(x[1], x[3]), d = csub(x[1], x[3]);
+        x[0] = cadd(t0, t2);
+        x[2] = csub(t0, t2);
+        x[1] = cadd_mi(t1, d);
+        x[3] = csub_mi(t1, d);
     }
 };
 
@@ -74,15 +121,14 @@ struct Dft<8> {
         Dft<4>::run(e);
         Dft<4>::run(o);
         // w8^1 = (1-i)/sqrt2, w8^2 = -i, w8^3 = (-1-i)/sqrt2
-        float2 o1 = make_float2((o[1].x + o[1].y) * B4D_SQRT1_2, (o[1].y - o[1].x) * B4D_SQRT1_2);
-        float2 o2 = cmul_mi(o[2]);
-        float2 o3 = make_float2((o[3].y - o[3].x) * B4D_SQRT1_2, -(o[3].x + o[3].y) * B4D_SQRT1_2);
+        float2 o1 = cmulc(o[1], B4D_SQRT1_2, -B4D_SQRT1_2);
+        float2 o3 = cmulc(o[3], -B4D_SQRT1_2, -B4D_SQRT1_2);
         x[0] = cadd(e[0], o[0]);
         x[4] = csub(e[0], o[0]);
         x[1] = cadd(e[1], o1);
         x[5] = csub(e[1], o1);
-        x[2] = cadd(e[2], o2);
-        x[6] = csub(e[2], o2);
+        x[2] = cadd_mi(e[2], o[2]);
+        x[6] = csub_mi(e[2], o[2]);
         x[3] = cadd(e[3], o3);
         x[7] = csub(e[3], o3);
     }
@@ -100,25 +146,22 @@ struct Dft<16> {
 #pragma unroll
             for (int k = 0; k < 4; ++k) s[r][k] = t[k];
         }
-        // twiddles w16^(r*k)
-        const float2 w1 = make_float2(B4D_C1_16, -B4D_S1_16);
-        const float2 w2 = make_float2(B4D_SQRT1_2, -B4D_SQRT1_2);
-        const float2 w3 = make_float2(B4D_S1_16, -B4D_C1_16);
-        const float2 w6 = make_float2(-B4D_SQRT1_2, -B4D_SQRT1_2);
-        const float2 w9 = make_float2(-B4D_C1_16, B4D_S1_16);
-        s[1][1] = cmul(s[1][1], w1);
-        s[1][2] = cmul(s[1][2], w2);
-        s[1][3] = cmul(s[1][3], w3);
-        s[2][1] = cmul(s[2][1], w2);
-        s[2][2] = cmul_mi(s[2][2]);
-        s[2][3] = cmul(s[2][3], w6);
-        s[3][1] = cmul(s[3][1], w3);
-        s[3][2] = cmul(s[3][2], w6);
-        s[3][3] = cmul(s[3][3], w9);
+        // twiddles w16^(r*k); s[2][2] keeps its factor -i for the final butterfly
+        s[1][1] = cmulc(s[1][1], B4D_C1_16, -B4D_S1_16);
+        s[1][2] = cmulc(s[1][2], B4D_SQRT1_2, -B4D_SQRT1_2);
+        s[1][3] = cmulc(s[1][3], B4D_S1_16, -B4D_C1_16);
+        s[2][1] = cmulc(s[2][1], B4D_SQRT1_2, -B4D_SQRT1_2);
+        s[2][3] = cmulc(s[2][3], -B4D_SQRT1_2, -B4D_SQRT1_2);
+        s[3][1] = cmulc(s[3][1], B4D_S1_16, -B4D_C1_16);
+        s[3][2] = cmulc(s[3][2], -B4D_SQRT1_2, -B4D_SQRT1_2);
+        s[3][3] = cmulc(s[3][3], -B4D_C1_16, B4D_S1_16);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float2 t[4] = {s[0][k], s[1][k], s[2][k], s[3][k]};
-            Dft<4>::run(t);
+            if (k == 2)
+                Dft<4>::run_mi2(t);
+            else
+                Dft<4>::run(t);
 #pragma unroll
             for (int q = 0; q < 4; ++q) x[k + 4 * q] = t[q];
         }
@@ -172,7 +215,12 @@ struct Fft3 {
         for (int i = 0; i < B1; ++i) {
             const int n1 = u + T * i;
 #pragma unroll
-            for (int k2 = 1; k2 < R1; ++k2) v[i + B1 * k2] = cmul(v[i + B1 * k2], tw[n1 * k2]);
+            for (int k2 = 1; k2 < R1; ++k2)
+#ifdef B4D_EXP_NOTW
+                v[i + B1 * k2] = cmulc(v[i + B1 * k2], 0.5f, 0.25f);
+#else
+                v[i + B1 * k2] = cmul(v[i + B1 * k2], tw[n1 * k2]);
+#endif
         }
     }
     // exchange 1: addr1(k2, n1) = k2*S1 + n1 ; stage-2 combos c = k2 + R1*m1, lane u handles c = u + T*i2
@@ -193,9 +241,15 @@ struct Fft3 {
         }
     }
     static __device__ __forceinline__ void xchg1(float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
+#ifndef B4D_EXP_NOXCHG
         xchg1_write(v, u, ci, lds);
+#endif
+#ifndef B4D_EXP_NOBAR
         __syncthreads();
+#endif
+#ifndef B4D_EXP_NOXCHG
         xchg1_read(v, u, ci, lds);
+#endif
     }
     // stage 2: DFT over m2, twiddle w_M^(m1*q2) = w_N^(R1*m1*q2)
     static __device__ __forceinline__ void stage2(float2 (&v)[E], int u, const float2* __restrict__ tw) {
@@ -205,7 +259,12 @@ struct Fft3 {
         for (int i2 = 0; i2 < B2; ++i2) {
             const int m1 = (u + T * i2) / R1;
 #pragma unroll
-            for (int q2 = 1; q2 < R2; ++q2) v[i2 + B2 * q2] = cmul(v[i2 + B2 * q2], tw[R1 * m1 * q2]);
+            for (int q2 = 1; q2 < R2; ++q2)
+#ifdef B4D_EXP_NOTW
+                v[i2 + B2 * q2] = cmulc(v[i2 + B2 * q2], 0.5f, 0.25f);
+#else
+                v[i2 + B2 * q2] = cmul(v[i2 + B2 * q2], tw[R1 * m1 * q2]);
+#endif
         }
     }
     // exchange 2: addr2(q2, m1, k2) = q2*S2 + c ; stage-3 butterflies A = k2 + R1*q2, lane u handles A = u + T*a
@@ -226,9 +285,15 @@ struct Fft3 {
         }
     }
     static __device__ __forceinline__ void xchg2(float2 (&v)[E], int u, int ci, float2* __restrict__ lds) {
+#ifndef B4D_EXP_NOXCHG
         xchg2_write(v, u, ci, lds);
+#endif
+#ifndef B4D_EXP_NOBAR
         __syncthreads();
+#endif
+#ifndef B4D_EXP_NOXCHG
         xchg2_read(v, u, ci, lds);
+#endif
     }
     // stage 3: outputs q1 -> register a + B3*q1  <->  k = u + T*(a + B3*q1)
     static __device__ __forceinline__ void stage3(float2 (&v)[E]) { butterflies<R3, E / R3, E / R3>(v); }

@@ -179,11 +179,13 @@ struct ColArgs {
 //               measured 1.23x faster than 512 lanes x 4 columns at 2 waves per SIMD)
 //   NY == 4096: CPT = 4 -> CT = 8 (a 16-column tile would need the whole register file)
 // __launch_bounds__(THREADS, 4) caps every variant at 128 VGPRs so that smaller NY run several workgroups per CU.
-template <int NY>
+// SPLIT workgroups share one memory tile (each takes CT / SPLIT adjacent columns of it): the layout keeps whole
+// 128-B lines per row while two 512-lane workgroups fit one CU and overlap each other's memory and butterfly phases.
+template <int NY, int SPLIT = 1>
 struct ColCfg {
     static constexpr int NC = 2;
-    static constexpr int CPT = NY == 4096 ? 4 : 8;
-    static constexpr int CT = NC * CPT;
+    static constexpr int CPT = (NY == 4096 ? 4 : 8) / SPLIT;
+    static constexpr int CT = NC * CPT * SPLIT;   // columns per MEMORY tile
     static constexpr int THREADS = CPT * (NY / E16);
     static constexpr int WAVES_PER_EU = THREADS >= 256 ? 4 : 1;
     using G = ColGeom<NY, CPT>;
@@ -205,22 +207,35 @@ __device__ __forceinline__ void store_cols(float2* __restrict__ rowp, const floa
 }
 
 // grid (nt, batch), block ColCfg<NY>::THREADS.
-template <int NY, int MODE>
-__global__ void __launch_bounds__(ColCfg<NY>::THREADS, ColCfg<NY>::WAVES_PER_EU) k_col(ColArgs p) {
-    using Cfg = ColCfg<NY>;
+template <int NY, int MODE, int SPLIT = 1>
+__global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLIT>::WAVES_PER_EU)) k_col(ColArgs p) {
+    using Cfg = ColCfg<NY, SPLIT>;
     using G = typename Cfg::G;
     constexpr int T = G::T, E = E16, NC = Cfg::NC, CPT = Cfg::CPT, CT = Cfg::CT;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int cp = threadIdx.x % CPT, u = threadIdx.x / CPT;
-    const int nt = gridDim.x;
-    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 when nt % 8 == 0).  Give each XCD a
-    // contiguous range of column tiles: the two 64-B halves of every 128-B PSD line are then written by
-    // neighbours on ONE XCD and merge in its L2 (speed only; any placement is correct).
-    const int ct = (nt % 8 == 0) ? (blockIdx.x % 8) * (nt / 8) + blockIdx.x / 8 : blockIdx.x;
-    const size_t frame = blockIdx.y;
+    const int nt = gridDim.x / SPLIT;
+    // Workgroups are dealt round-robin over the 8 XCDs (linear workgroup id % 8).  Neighbouring column tiles write
+    // the two 64-B halves of every 128-B PSD line and share the 64-B sectors of the Hermitian-mirror stores (the
+    // mirror of 16 aligned columns is misaligned by one float): those merge only in a common L2.  With batch % 8 == 0
+    // every tile of frame f runs on XCD f % 8 (measured -6% on the 2048^2 kernel against per-XCD tile ranges, which
+    // leave one tile boundary in eight split across two L2s); otherwise each XCD takes a contiguous tile range.
+    // Speed only: any placement is correct.  The SPLIT parts of a tile are consecutive workgroups of one XCD.
+    int slot, fr;
+    if (gridDim.y % 8 == 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, k = lin / 8;
+        fr = 8 * (k / gridDim.x) + lin % 8;
+        slot = k % gridDim.x;
+    } else {
+        slot = (nt % 8 == 0) ? (blockIdx.x % 8) * (nt * SPLIT / 8) + blockIdx.x / 8 : blockIdx.x;
+        fr = blockIdx.y;
+    }
+    const int ct = slot / SPLIT;
+    const int cpm = cp + CPT * (slot % SPLIT);   // lane position across the memory tile
+    const size_t frame = fr;
     const int nx = p.nx;
     float2* tile = p.spec + ((frame * nt + ct) * (size_t)NY) * CT;
-    const unsigned toff = (unsigned)u * CT + NC * cp;  // element offset of (row u, first column of this lane)
+    const unsigned toff = (unsigned)u * CT + NC * cpm;  // element offset of (row u, first column of this lane)
     float2 v[NC][E];
     B4D_STAMP(0);
     // column pairs in issue order: the first pair's loads complete first, so its butterflies start while the
@@ -239,7 +254,7 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS, ColCfg<NY>::WAVES_PER_EU)
     Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL, MODE != COL_PSD_AC, Cfg::SB>(v, u, cp, lds, p.tw);
     B4D_STAMP(2);
     // v[c][j] = F[ky = u + T j][kx0 + c]   (COL_PSD_AC: after the stage-3 butterflies done below)
-    const int kx0 = ct * CT + NC * cp;
+    const int kx0 = ct * CT + NC * cpm;
 
     if (MODE == COL_FORWARD) {  // keep the 2-D half spectrum in the tile
 #pragma unroll
@@ -307,9 +322,23 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS, ColCfg<NY>::WAVES_PER_EU)
                     m.w = pw[0] * s;
                     *reinterpret_cast<float4_u*>(&psd[rm + nx / 2 - kx0 - 3]) = m;
                 } else {
+#if defined(B4D_EXP_NOMIRROR)
+#elif defined(B4D_EXP_ALIGNED_MIRROR)
+                    *reinterpret_cast<float2*>(&psd[rm + nx / 2 - kx0 - 2]) = make_float2(pw[1] * s, pw[0] * s);
+#elif defined(B4D_PAIR_MIRROR)
+                    // columns nx/2 - kx descend as kx ascends: the 8-byte aligned pairs are (kx0 + 2, kx0 + 1), i.e. the
+                    // next lane's first column and this lane's second
+                    const float nb = __shfl_down(pw[0], 1, 64);
+                    if (cpm < CT / NC - 1)
+                        *reinterpret_cast<float2*>(&psd[rm + nx / 2 - kx0 - 2]) = make_float2(nb * s, pw[1] * s);
+                    else
+                        psd[rm + nx / 2 - kx0 - 1] = pw[1] * s;
+                    if (cpm == 0 && kx0 >= 1) psd[rm + nx / 2 - kx0] = pw[0] * s;
+#else
 #pragma unroll
                     for (int k = 0; k < NC; ++k)
                         if (kx0 + k >= 1) psd[rm + nx / 2 - kx0 - k] = pw[k] * s;
+#endif
                 }
             }
             // inverse inputs, already (im, re)-swapped so that the forward code inverts: Pa + i Pb -> (Pb, Pa)
@@ -645,17 +674,21 @@ static inline int make_twiddles(int n, float2** out) {
         case 4096: return CALL(4096);   \
     }
 
+#ifndef B4D_COL_SPLIT
+#define B4D_COL_SPLIT 1
+#endif
 template <int NY, int MODE>
 static int launch_col(const ColArgs& a, int ntiles, int batch, hipStream_t st) {
-    using Cfg = ColCfg<NY>;
+    constexpr int SPLIT = (NY == 2048 && MODE == COL_PSD_AC) ? B4D_COL_SPLIT : 1;
+    using Cfg = ColCfg<NY, SPLIT>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col<NY, MODE>),
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col<NY, MODE, SPLIT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     });
     B4D_HIP(attr_err);
-    hipLaunchKernelGGL((k_col<NY, MODE>), dim3(ntiles, batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_col<NY, MODE, SPLIT>), dim3(ntiles * SPLIT, batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
