@@ -54,6 +54,10 @@ SIGNATURES = {
     "b4d_temporal_finalize": (_i, [_vp, _vp, _d, _sz, _vp, _vp, _vp, _vp]),
     "b4d_moments": (_i, [_vp, _i, _sz, _d, _d, _vp, _vp]),
     "b4d_sobel_laplace_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "b4d_stack_mean_f32": (_i, [_vp, _i, _sz, _vp, _vp]),
+    "b4d_flat_den": (_i, [_vp, _vp, _sz, _f, _i, _vp, _vp]),
+    "b4d_flat_field": (_i, [_vp, _i, _sz, _vp, _vp, _f, _f, _i, _vp, _vp]),
+    "b4d_repair_pixels": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "b4d_sta2_eigenvalues": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "b4d_percentiles": (_i, [_vp, _i, _sz, _vp, _i, _vp, _vp]),
     "b4d_radial_profile": (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _vp]),

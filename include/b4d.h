@@ -119,6 +119,20 @@ int b4d_moments(const float* frames, int batch, size_t npix, double eps, double 
  * out: (batch, 4) float64 {mean(gx^2), mean(gy^2), mean(lap), mean(lap^2)} over finite pixels. */
 int b4d_sobel_laplace_stats(const float* frames, int batch, int ny, int nx, double* out, void* stream);
 
+/* preprocessing/normalize.py:12-145 flat_field_correction, float32 arithmetic in the reference's order:
+ *   b4d_stack_mean_f32   :86-93  mean of a (frames, npix) flat / dark stack along axis 0 (NumPy's float32 reduction
+ *                                order: sequential adds in frame order, one division)
+ *   b4d_flat_den         :107-113 den = F - D (D = 0 when dark is null); mask_bad != 0 writes NaN where den <= eps
+ *                                (input of the median / mean selections, which skip NaN)
+ *   b4d_flat_field       :115-132 out = ((I - D) / (F - D)) * scale, 0 where F - D <= eps; flat null: I - D
+ *   b4d_repair_pixels    :134-140 replaces the listed pixels (idx: DEVICE int64 linear indices into one frame) by the
+ *                                3x3 median (scipy "reflect") of the frame as it was on entry.  Synchronises the stream. */
+int b4d_stack_mean_f32(const float* stack, int frames, size_t npix, float* out, void* stream);
+int b4d_flat_den(const float* flat, const float* dark, size_t npix, float eps, int mask_bad, float* den, void* stream);
+int b4d_flat_field(const float* frames, int batch, size_t npix, const float* flat, const float* dark, float eps, float scale,
+                   int apply_scale, float* out, void* stream);
+int b4d_repair_pixels(float* frames, int batch, int ny, int nx, const long long* idx, int nbad, void* stream);
+
 /* metrics/sharpness.py:752-861 eigenvalues (STA2): J = (x - mean(x)) / ||x||_2, eig_i = s_i(J)^2 / (M N - 1).
  * The reference takes every singular value from LAPACK and uses the first k (default 5); this returns the leading
  * nout (<= 8) of them, descending, from the Gram matrix of the smaller side (MFMA) and a 32-vector block subspace

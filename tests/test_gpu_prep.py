@@ -1,0 +1,67 @@
+"""GPU tier: flat_field_correction through the C ABI against the oracle and the reference's golden outputs."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "prep.npz"))
+
+
+@pytest.fixture(scope="module")
+def prep():
+    from barc4dip_amd import preprocessing
+    return preprocessing
+
+
+def _cases():
+    from test_prep_oracle import cases
+    return cases()
+
+
+@pytest.mark.parametrize("name", ["default", "none", "repair", "eps50", "single", "flat_only", "dark_only", "neither", "f32_in"])
+def test_flat_field_bit_exact(prep, name):
+    """float32 arithmetic in the reference's order: identical bits (normalize.py:12-145)."""
+    img, kw = _cases()[name]
+    out = prep.flat_field_correction(img, **kw)
+    assert isinstance(out, np.ndarray) and out.dtype == np.float32 and out.shape == G[name].shape
+    assert np.array_equal(out, G[name], equal_nan=True)
+
+
+def test_flat_mean_scale(prep):
+    """flat_mean: NumPy sums the valid denominators pairwise in float32, the kernel in float64: <= 1 ulp of the scale
+    factor, i.e. 2^-23 relative plus one rounding on the output."""
+    img, kw = _cases()["mean"]
+    out = prep.flat_field_correction(img, **kw)
+    np.testing.assert_allclose(out, G["mean"], rtol=3e-7, atol=0)
+    assert np.array_equal(out == 0, G["mean"] == 0)
+
+
+def test_flat_field_large_vs_oracle(prep):
+    from barc4dip_amd import synth
+    from oracle import preprocess_np as P
+
+    rng = np.random.default_rng(11)
+    n = 512
+    imgs = np.stack([synth.speckle_frame(n, 70 + i) for i in range(3)]).astype(np.uint16)
+    gain = 1.0 + 0.2 * np.sin(np.arange(n) / 13.0)[None, :] * np.cos(np.arange(n) / 17.0)[:, None]
+    flats = rng.poisson(3000 * gain[None] + 90, size=(4, n, n)).astype(np.uint16)
+    darks = rng.poisson(90, size=(6, n, n)).astype(np.uint16)
+    flats[:, rng.integers(0, n, 40), rng.integers(0, n, 40)] = 0
+    flats[:, 0, :7] = 0
+    flats[:, -1, -3:] = 0
+    for kw in (dict(), dict(bad_pixel_removal=True), dict(scale="none", eps=10.0, bad_pixel_removal=True)):
+        got = prep.flat_field_correction(imgs, flats=flats, darks=darks, **kw)
+        want = P.flat_field_correction(imgs, flats=flats, darks=darks, **kw)
+        assert np.array_equal(got, want, equal_nan=True), kw
+
+
+def test_flat_field_errors(prep):
+    im = G["imgs"]
+    with pytest.raises(ValueError):
+        prep.flat_field_correction(im, flats=G["flats"], scale="median")
+    with pytest.raises(ValueError):
+        prep.flat_field_correction(im[0, 0], flats=G["flats"])
+    with pytest.raises(ValueError):
+        prep.flat_field_correction(im, flats=G["flats"][None])
