@@ -50,6 +50,7 @@ SIGNATURES = {
     "b4d_psd_autocorr2d_timed": (_i, [_vp, _vp, _i, _vp, _f, _vp, _u, _vp, _vp]),
     "b4d_xcorr2d": (_i, [_vp, _vp, _vp, _i, _vp, _u, _vp]),
     "b4d_phase_correlation": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _d, _vp, _vp, _vp]),
+    "b4d_template_match": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
     "b4d_temporal_accumulate": (_i, [_vp, _i, _sz, _vp, _vp, _vp]),
     "b4d_temporal_finalize": (_i, [_vp, _vp, _d, _sz, _vp, _vp, _vp, _vp]),
     "b4d_moments": (_i, [_vp, _i, _sz, _d, _d, _vp, _vp]),

@@ -112,6 +112,12 @@ struct FinArgs {
     int* peak_ij;           // (pairs, 2) or null
     int ny, nx, nblk, subpixel;
     double eps;
+    // template matching: the map of pair i is geom[4 i] x geom[4 i + 1] values (row-major, compact) at mag + i * stride,
+    // shifts are counted from (geom[4 i + 2], geom[4 i + 3]), the median runs over med_src (|map|).  Null / 0 for
+    // phase correlation: ny x nx maps, origin (ny/2, nx/2), median of the map itself.
+    const int* geom;
+    const float* med_src;
+    size_t stride;
 };
 
 // grid (pairs), block 1024
@@ -121,10 +127,19 @@ __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
     __shared__ float sv[16];
     __shared__ int si[16];
     const size_t pair = blockIdx.x;
-    const unsigned n = (unsigned)p.ny * p.nx;
-    const float* mag = p.mag + pair * (size_t)n;
+    int mny = p.ny, mnx = p.nx, oy = p.ny / 2, ox = p.nx / 2;
+    if (p.geom) {
+        mny = p.geom[4 * pair];
+        mnx = p.geom[4 * pair + 1];
+        oy = p.geom[4 * pair + 2];
+        ox = p.geom[4 * pair + 3];
+    }
+    const unsigned n = (unsigned)mny * mnx;
+    const size_t stride = p.stride ? p.stride : (size_t)n;
+    const float* mag = p.mag + pair * stride;
+    const float* msrc = p.med_src ? p.med_src + pair * stride : mag;
     // ---- arg-max over the per-workgroup partials (first occurrence in row-major order)
-    float bv = -1.f;
+    float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < p.nblk; i += blockDim.x)
         argmax_merge(bv, bi, p.part_val[pair * p.nblk + i], p.part_idx[pair * p.nblk + i]);
@@ -148,21 +163,21 @@ __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
     unsigned nl, ne;
     float med;
     if (n & 1u) {
-        med = key2f(radix_select(mag, n, n / 2, hist, sh, nl, ne));
+        med = key2f(radix_select(msrc, n, n / 2, hist, sh, nl, ne));
     } else {
-        const unsigned ka = radix_select(mag, n, n / 2 - 1, hist, sh, nl, ne);
+        const unsigned ka = radix_select(msrc, n, n / 2 - 1, hist, sh, nl, ne);
         float a = key2f(ka), b = a;
-        if (nl + ne <= n / 2) b = key2f(next_larger_key(mag, n, ka, hist));  // upper middle value = next larger element
+        if (nl + ne <= n / 2) b = key2f(next_larger_key(msrc, n, ka, hist));  // upper middle value = next larger element
         med = __fmul_rn(__fadd_rn(a, b), 0.5f);
     }
     if (threadIdx.x != 0) return;
     // ---- peak quality + Taylor step, op for op like tracking.py:314-375 (float32 scalars, no contraction)
-    const int mi = bi / p.nx, mj = bi % p.nx;
+    const int mi = bi / mnx, mj = bi % mnx;
     const double peak = (double)bv;
     const double snr = fabs(peak) / ((double)med + p.eps);
-    double dy = (double)(mi - p.ny / 2), dx = (double)(mj - p.nx / 2);
-    if (p.subpixel && mi > 0 && mi < p.ny - 1 && mj > 0 && mj < p.nx - 1) {
-        auto c = [&](int di, int dj) { return mag[(size_t)(mi + di) * p.nx + (mj + dj)]; };
+    double dy = (double)(mi - oy), dx = (double)(mj - ox);
+    if (p.subpixel && mi > 0 && mi < mny - 1 && mj > 0 && mj < mnx - 1) {
+        auto c = [&](int di, int dj) { return mag[(size_t)(mi + di) * mnx + (mj + dj)]; };
         const float c00 = c(0, 0);
         const float gy = __fdiv_rn(__fsub_rn(c(1, 0), c(-1, 0)), 2.0f);
         const float hyy = __fsub_rn(__fadd_rn(c(1, 0), c(-1, 0)), __fmul_rn(2.0f, c00));
@@ -187,6 +202,175 @@ __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
     if (p.peak_ij) {
         p.peak_ij[pair * 2] = mi;
         p.peak_ij[pair * 2 + 1] = mj;
+    }
+}
+
+// ------------------------------------------------------------------------------------ NCC template matching
+// Summed-area tables (float64) of the image as the matcher sees it, v = (x - mean) / denom in float32 (raw image:
+// mean 0, denom 1), and of v^2: sat[(y + 1) (nx + 1) + x + 1] = sum over rows <= y, columns <= x.
+// Row pass: grid (ny, nimg), block 256; column pass: grid (ceil((nx + 1) / 64), nimg), block 64.
+__global__ void __launch_bounds__(256) k_sat_rows(const float* __restrict__ frames, int ny, int nx, const RowSrc* __restrict__ srcs,
+                                                  double* __restrict__ sat1, double* __restrict__ sat2) {
+    __shared__ double s1[256], s2[256];
+    const RowSrc sd = srcs[blockIdx.y];
+    const int y = blockIdx.x, per = (nx + 255) / 256;
+    const float* row = frames + ((size_t)sd.frame * ny + y) * nx;
+    const size_t W1 = (size_t)nx + 1, base = (size_t)blockIdx.y * (ny + 1) * W1;
+    double a1 = 0.0, a2 = 0.0;
+    const int x0 = threadIdx.x * per, x1 = min(nx, x0 + per);
+    for (int x = x0; x < x1; ++x) {
+        const double v = (double)((row[x] - sd.mean) / sd.denom);
+        a1 += v;
+        a2 = fma(v, v, a2);
+    }
+    s1[threadIdx.x] = a1;
+    s2[threadIdx.x] = a2;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan of the per-thread sums
+        const double t1 = threadIdx.x >= o ? s1[threadIdx.x - o] : 0.0, t2 = threadIdx.x >= o ? s2[threadIdx.x - o] : 0.0;
+        __syncthreads();
+        s1[threadIdx.x] += t1;
+        s2[threadIdx.x] += t2;
+        __syncthreads();
+    }
+    double r1 = s1[threadIdx.x] - a1, r2 = s2[threadIdx.x] - a2;  // exclusive prefix of this thread's segment
+    double* o1 = sat1 + base + (size_t)(y + 1) * W1;
+    double* o2 = sat2 + base + (size_t)(y + 1) * W1;
+    for (int x = x0; x < x1; ++x) {
+        const double v = (double)((row[x] - sd.mean) / sd.denom);
+        r1 += v;
+        r2 = fma(v, v, r2);
+        o1[x + 1] = r1;
+        o2[x + 1] = r2;
+    }
+    if (threadIdx.x == 0) {
+        o1[0] = 0.0;
+        o2[0] = 0.0;
+    }
+    if (y == 0)
+        for (int x = threadIdx.x; x <= nx; x += 256) {
+            sat1[base + x] = 0.0;
+            sat2[base + x] = 0.0;
+        }
+}
+
+__global__ void __launch_bounds__(64) k_sat_cols(int ny, int nx, double* __restrict__ sat1, double* __restrict__ sat2) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x > nx) return;
+    const size_t W1 = (size_t)nx + 1, base = (size_t)blockIdx.y * (ny + 1) * W1;
+    double r1 = 0.0, r2 = 0.0;
+    for (int y = 1; y <= ny; ++y) {
+        const size_t o = base + (size_t)y * W1 + x;
+        r1 += sat1[o];
+        r2 += sat2[o];
+        sat1[o] = r1;
+        sat2[o] = r2;
+    }
+}
+
+// template statistics of the z-scored float32 template: tstat[2 k] = mean, tstat[2 k + 1] = sum (z - mean)^2.
+// grid (ntpl), block 1024
+__global__ void __launch_bounds__(1024) k_tpl_stats(const float* __restrict__ frames, int ny, int nx, const RowSrc* __restrict__ srcs,
+                                                    double* __restrict__ tstat) {
+    __shared__ double sh[32];
+    const RowSrc sd = srcs[blockIdx.x];
+    const int h = sd.y1 - sd.y0, w = sd.x1 - sd.x0, n = h * w;
+    const float* f = frames + (size_t)sd.frame * ny * nx;
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double v = (double)((f[(size_t)(sd.y0 + i / w) * nx + sd.x0 + i % w] - sd.mean) / sd.denom);
+        a1 += v;
+        a2 = fma(v, v, a2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a1 += __shfl_down(a1, o, 64);
+        a2 += __shfl_down(a2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = a1;
+        sh[16 + (threadIdx.x >> 6)] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int i = 0; i < 16; ++i) {
+            t1 += sh[i];
+            t2 += sh[16 + i];
+        }
+        const double mean = t1 / n;
+        tstat[2 * blockIdx.x] = mean;
+        tstat[2 * blockIdx.x + 1] = fmax(t2 - n * mean * mean, 0.0);
+    }
+}
+
+struct NccArgs {
+    const float* xc;      // (pairs, ny, nx) shifted circular cross-correlation sum I[p + d] T[p], d = index - (ny/2, nx/2)
+    const double* sat1;   // (nimg, ny + 1, nx + 1)
+    const double* sat2;
+    const int* pair_img;
+    const int* pair_tpl;
+    const RowSrc* tsrc;   // template descriptors (ROI = reference position)
+    const double* tstat;
+    float* ncc;           // (pairs, stride): compact (ny - h + 1, nx - w + 1) maps
+    float* absncc;
+    float* part_val;      // (pairs, nblk)
+    int* part_idx;
+    int* geom;            // (pairs, 4) map rows, columns, origin (y0, x0) for the epilogue
+    int ny, nx, nblk;
+    int img_h, img_w;     // extent of the images inside the (ny, nx) canvas (zero beyond)
+};
+
+// zero-mean normalised cross-correlation at every "valid" window position (signal/tracking.py:157-167: the arithmetic
+// of cv2.TM_CCOEFF_NORMED / skimage.match_template).  grid (nblk, pairs), block 256
+__global__ void __launch_bounds__(256) k_ncc_map(NccArgs p) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int pair = blockIdx.y;
+    const RowSrc ts = p.tsrc[p.pair_tpl[pair]];
+    const int h = ts.y1 - ts.y0, w = ts.x1 - ts.x0, hv = p.img_h - h + 1, wv = p.img_w - w + 1, n = hv * wv;
+    const double tmean = p.tstat[2 * p.pair_tpl[pair]], tssd = p.tstat[2 * p.pair_tpl[pair] + 1], vol = (double)h * w;
+    const size_t W1 = (size_t)p.nx + 1, fpix = (size_t)p.ny * p.nx;
+    const double* s1 = p.sat1 + (size_t)p.pair_img[pair] * (p.ny + 1) * W1;
+    const double* s2 = p.sat2 + (size_t)p.pair_img[pair] * (p.ny + 1) * W1;
+    const float* xc = p.xc + pair * fpix;
+    const int per = (n + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * per, e1 = min(n, e0 + per);
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int i = e / wv, j = e % wv;
+        const size_t a = (size_t)i * W1 + j, b = (size_t)(i + h) * W1 + j;
+        const double S1 = s1[b + w] - s1[a + w] - s1[b] + s1[a];
+        const double S2 = s2[b + w] - s2[a + w] - s2[b] + s2[a];
+        const int yy = (p.ny / 2 + i - ts.y0) & (p.ny - 1), xx = (p.nx / 2 + j - ts.x0) & (p.nx - 1);
+        const double num = (double)xc[(size_t)yy * p.nx + xx] - S1 * tmean;
+        const double den = sqrt(fmax((S2 - S1 * S1 / vol) * tssd, 0.0));
+        const float r = den > 1.1920928955078125e-07 ? (float)(num / den) : 0.f;
+        p.ncc[pair * fpix + e] = r;
+        p.absncc[pair * fpix + e] = fabsf(r);
+        argmax_merge(bv, bi, r, e);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_down(bv, o, 64);
+        const int oi = __shfl_down(bi, o, 64);
+        argmax_merge(bv, bi, ov, oi);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sv[threadIdx.x >> 6] = bv;
+        si[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) argmax_merge(bv, bi, sv[k], si[k]);
+        p.part_val[(size_t)pair * gridDim.x + blockIdx.x] = bv;
+        p.part_idx[(size_t)pair * gridDim.x + blockIdx.x] = bi;
+        if (blockIdx.x == 0) {
+            p.geom[4 * pair] = hv;
+            p.geom[4 * pair + 1] = wv;
+            p.geom[4 * pair + 2] = ts.y0;
+            p.geom[4 * pair + 3] = ts.x0;
+        }
     }
 }
 
@@ -491,6 +675,153 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         fa.eps = eps;
         hipLaunchKernelGGL(k_track_fin, dim3(np), dim3(1024), 0, st, fa);
         B4D_HIP(hipGetLastError());
+    }
+    return B4D_OK;
+}
+
+int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float* tpl_src, int ntplsrc,
+                       const int32_t* tpl_frame, const int32_t* tpl_roi, int ntpl, const int32_t* pair_img,
+                       const int32_t* pair_tpl, int npairs, int img_h, int img_w, int zscore_image, int subpixel, double eps,
+                       double* out, int32_t* peak_ij, void* stream) {
+    if (!pl || !images || !tpl_src || !tpl_frame || !tpl_roi || !pair_img || !pair_tpl || !out)
+        return fail(B4D_EINVAL, "null argument");
+    if (nimg < 1 || ntplsrc < 1 || ntpl < 1 || npairs < 1) return fail(B4D_EINVAL, "counts must be >= 1");
+    if (pl->general) return fail(B4D_ESIZE, "template matching needs a power-of-two canvas: ny, nx in [64, 4096]");
+    const int ny = pl->ny, nx = pl->nx;
+    if (img_h <= 0) img_h = ny;
+    if (img_w <= 0) img_w = nx;
+    if (img_h > ny || img_w > nx) return fail(B4D_EINVAL, "image extent exceeds the canvas");
+    for (int k = 0; k < ntpl; ++k) {
+        const int32_t* r = tpl_roi + 4 * k;
+        if (tpl_frame[k] < 0 || tpl_frame[k] >= ntplsrc || r[0] < 0 || r[1] > img_h || r[0] >= r[1] || r[2] < 0 || r[3] > img_w ||
+            r[2] >= r[3])
+            return fail(B4D_EINVAL, "template " + std::to_string(k) + ": frame or ROI out of range");
+    }
+    for (int i = 0; i < npairs; ++i)
+        if (pair_img[i] < 0 || pair_img[i] >= nimg || pair_tpl[i] < 0 || pair_tpl[i] >= ntpl)
+            return fail(B4D_EINVAL, "pair " + std::to_string(i) + ": index out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t fpix = (size_t)ny * nx, half = fpix / 2, satn = (size_t)(ny + 1) * (nx + 1);
+    const int pc = std::max(1, std::min(npairs, pl->chunk * 2));
+    const int nsrc = nimg + ntpl, nblk = 256;
+    size_t need = 0;
+    auto add = [&](size_t b) { need += ((b + 255) & ~(size_t)255) + 256; };
+    add(sizeof(float2) * half * nsrc);
+    add(sizeof(float2) * (size_t)ny * nsrc);
+    add(sizeof(float) * (size_t)ny * nsrc);
+    add(sizeof(RowSrc) * nsrc);
+    add(sizeof(int) * 3 * (size_t)npairs);
+    add(sizeof(double) * satn * nimg);
+    add(sizeof(double) * satn * nimg);
+    add(sizeof(double) * 2 * (size_t)ntpl);
+    add(sizeof(float2) * half * pc);
+    add(sizeof(float) * (size_t)ny * pc);
+    for (int i = 0; i < 3; ++i) add(sizeof(float) * fpix * pc);
+    add(sizeof(float) * (size_t)nblk * pc);
+    add(sizeof(int) * (size_t)nblk * pc);
+    add(sizeof(int) * 4 * (size_t)pc);
+    Arena ar;
+    int rc = track_arena(pl, need, &ar);
+    if (rc) return rc;
+    float2* spec = ar.take<float2>(half * nsrc);
+    float2* nyq = ar.take<float2>((size_t)ny * nsrc);
+    float* nyq_rows = ar.take<float>((size_t)ny * nsrc);
+    RowSrc* srcs = ar.take<RowSrc>(nsrc);
+    int* pidx = ar.take<int>(3 * (size_t)npairs);
+    int* sidx = pidx + 2 * (size_t)npairs;
+    double* sat1 = ar.take<double>(satn * nimg);
+    double* sat2 = ar.take<double>(satn * nimg);
+    double* tstat = ar.take<double>(2 * (size_t)ntpl);
+    float2* g = ar.take<float2>(half * pc);
+    float* gnyq = ar.take<float>((size_t)ny * pc);
+    float* xc = ar.take<float>(fpix * pc);
+    float* ncc = ar.take<float>(fpix * pc);
+    float* absncc = ar.take<float>(fpix * pc);
+    float* pval = ar.take<float>((size_t)nblk * pc);
+    int* pind = ar.take<int>((size_t)nblk * pc);
+    int* geom = ar.take<int>(4 * (size_t)pc);
+
+    std::vector<RowSrc> h(nsrc);
+    for (int i = 0; i < nimg; ++i) h[i] = RowSrc{i, 0, img_h, 0, img_w, 0.f, 1.f, 0};
+    for (int k = 0; k < ntpl; ++k)
+        h[nimg + k] = RowSrc{tpl_frame[k], tpl_roi[4 * k], tpl_roi[4 * k + 1], tpl_roi[4 * k + 2], tpl_roi[4 * k + 3], 0.f, 1.f, 0};
+    std::vector<int> hp(3 * (size_t)npairs);
+    for (int i = 0; i < npairs; ++i) {
+        hp[i] = pair_img[i];
+        hp[npairs + i] = pair_tpl[i];
+        hp[2 * (size_t)npairs + i] = nimg + pair_tpl[i];  // templates sit after the images in `spec`
+    }
+    B4D_HIP(hipMemcpyAsync(srcs, h.data(), sizeof(RowSrc) * nsrc, hipMemcpyHostToDevice, st));
+    B4D_HIP(hipMemcpyAsync(pidx, hp.data(), sizeof(int) * hp.size(), hipMemcpyHostToDevice, st));
+    B4D_HIP(hipStreamSynchronize(st));
+    // "opencv": the image is z-scored as a whole (tracking.py:157); "skimage": raw float32 image (tracking.py:166)
+    if (zscore_image) hipLaunchKernelGGL(k_roi_stats, dim3(nimg), dim3(1024), 0, st, images, ny, nx, eps, srcs);
+    hipLaunchKernelGGL(k_roi_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, eps, srcs + nimg);
+    hipLaunchKernelGGL(k_tpl_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, srcs + nimg, tstat);
+    hipLaunchKernelGGL(k_sat_rows, dim3(ny, nimg), dim3(256), 0, st, images, ny, nx, srcs, sat1, sat2);
+    hipLaunchKernelGGL(k_sat_cols, dim3((nx + 64) / 64, nimg), dim3(64), 0, st, ny, nx, sat1, sat2);
+    B4D_HIP(hipGetLastError());
+    const int fc = std::max(1, pl->chunk * 2);
+    for (int i0 = 0; i0 < nimg; i0 += fc) {
+        const int n = std::min(fc, nimg - i0);
+        if ((rc = forward_spectra(pl, images, srcs + i0, n, spec + half * i0, nyq_rows + (size_t)ny * i0, nyq + (size_t)ny * i0, st)))
+            return rc;
+    }
+    for (int k0 = 0; k0 < ntpl; k0 += fc) {
+        const int n = std::min(fc, ntpl - k0), o = nimg + k0;
+        if ((rc = forward_spectra(pl, tpl_src, srcs + o, n, spec + half * o, nyq_rows + (size_t)ny * o, nyq + (size_t)ny * o, st)))
+            return rc;
+    }
+    {
+        for (int p0 = 0; p0 < npairs; p0 += pc) {
+            const int np = std::min(pc, npairs - p0);
+            int r2 = product_inverse<false>(pl, spec, nyq, pidx + p0, sidx + p0, spec, nyq, np, g, gnyq, 0.f, 0u, st);
+            if (r2) return r2;
+            RowOutArgs ra{};
+            ra.g = g;
+            ra.gnyq = gnyq;
+            ra.out = xc;
+            ra.tw = pl->tw_x;
+            ra.scale = 1.0f / ((float)nx * (float)ny);
+            ra.ny = ny;
+            ra.ct_w = pl->ct_w;
+            if ((r2 = dispatch_c2r(pl, ra, np, st, C2R_OUT))) return r2;
+            NccArgs na{};
+            na.xc = xc;
+            na.sat1 = sat1;
+            na.sat2 = sat2;
+            na.pair_img = pidx + p0;
+            na.pair_tpl = pidx + npairs + p0;
+            na.tsrc = srcs + nimg;
+            na.tstat = tstat;
+            na.ncc = ncc;
+            na.absncc = absncc;
+            na.part_val = pval;
+            na.part_idx = pind;
+            na.geom = geom;
+            na.ny = ny;
+            na.nx = nx;
+            na.nblk = nblk;
+            na.img_h = img_h;
+            na.img_w = img_w;
+            hipLaunchKernelGGL(k_ncc_map, dim3(nblk, np), dim3(256), 0, st, na);
+            FinArgs fa{};
+            fa.mag = ncc;
+            fa.med_src = absncc;
+            fa.geom = geom;
+            fa.stride = fpix;
+            fa.part_val = pval;
+            fa.part_idx = pind;
+            fa.out = out + (size_t)p0 * 4;
+            fa.peak_ij = peak_ij ? peak_ij + (size_t)p0 * 2 : nullptr;
+            fa.ny = ny;
+            fa.nx = nx;
+            fa.nblk = nblk;
+            fa.subpixel = subpixel;
+            fa.eps = eps;
+            hipLaunchKernelGGL(k_track_fin, dim3(np), dim3(1024), 0, st, fa);
+            B4D_HIP(hipGetLastError());
+        }
     }
     return B4D_OK;
 }

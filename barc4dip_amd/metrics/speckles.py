@@ -6,8 +6,8 @@ polar radial profile, PSD disc statistics, phase-correlation tracking; only the 
 thousand samples stay on the host.  Differences: device arithmetic is float32; FFT-based
 groups need power-of-two frame sizes, so FFT-based TILE statistics (170/171- or 227/228-pixel tiles) are
 skipped with a RuntimeWarning until general-length plans exist; the default tracker of the reference
-(`tracking_method="template"`, scikit-image) is unavailable like in the reference without that library --
-use ``tracking_method="phase", tracking_backend="internal"``.
+(`tracking_method="template"`, cv2 / scikit-image NCC) runs on the device through ``b4d_template_match`` (parity with
+those libraries is unpinned: they are absent from the build image, the oracle follows their published definition).
 """
 from __future__ import annotations
 
@@ -24,7 +24,7 @@ from ..maths.radial import radial_mean_binned, radial_profile_batch
 from ..maths.stats import distance_at_fraction_from_peak, width_at_fraction
 from ..signal import corr as _corr
 from ..signal import fft as _fft
-from ..signal.tracking import phase_correlation_batch
+from ..signal.tracking import phase_correlation_batch, template_matching_batch
 from . import kernels as K
 from .common import (apply_display_origin, choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
                      tile_spans, tiles_meta)
@@ -297,15 +297,13 @@ def speckle_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "al
     if method == "template":
         if tracking_backend not in ("opencv", "skimage"):
             raise ValueError("backend must be 'opencv' or 'skimage'.")
-        raise ImportError(f"backend={tracking_backend!r} requires "
-                          f"{'opencv-python (cv2)' if tracking_backend == 'opencv' else 'scikit-image'}; "
-                          "use tracking_method='phase', tracking_backend='internal' for the GPU tracker.")
-    if method != "phase":
+    elif method == "phase":
+        if tracking_backend == "skimage":
+            raise ImportError("backend='skimage' requires scikit-image.")
+        if tracking_backend != "internal":
+            raise ValueError("backend must be 'internal' or 'skimage'.")
+    else:
         raise ValueError(f"Unsupported tracking method: {tracking_method!r}. Supported: phase, template")
-    if tracking_backend == "skimage":
-        raise ImportError("backend='skimage' requires scikit-image.")
-    if tracking_backend != "internal":
-        raise ValueError("backend must be 'internal' or 'skimage'.")
 
     per_frame = [speckle_stats(stack[t], metrics=metrics, tiles=tiles, display_origin=display_origin,
                                saturation_value=saturation_value, eps=eps, verbose=False) for t in range(T)]
@@ -329,7 +327,11 @@ def speckle_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "al
     pair_img = [t for t in range(T) for _ in range(9)] * 2
     pair_tpl = [k for _ in range(T) for k in range(9)] + [9 + 9 * t + k for t in range(T) for k in range(9)]
     dev, _, _ = D.to_device_f32(stack, ndim=(3,))
-    res = phase_correlation_batch(dev, dev, tpl_frame, tpl_roi, pair_img, pair_tpl, subpixel=subpixel, eps=1e-9)
+    if method == "template":
+        res = template_matching_batch(dev, dev, tpl_frame, tpl_roi, pair_img, pair_tpl, backend=tracking_backend,
+                                      subpixel=subpixel, eps=1e-9)
+    else:
+        res = phase_correlation_batch(dev, dev, tpl_frame, tpl_roi, pair_img, pair_tpl, subpixel=subpixel, eps=1e-9)
     dy_abs = res[:9 * T, 0].reshape(T, 3, 3).astype(np.float32)
     dx_abs = res[:9 * T, 1].reshape(T, 3, 3).astype(np.float32)
     dy_inc = res[9 * T:, 0].reshape(T, 3, 3).astype(np.float32)

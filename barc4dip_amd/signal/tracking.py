@@ -8,8 +8,12 @@ first-occurrence arg-max, peak, exact median SNR and the 3x3 Taylor step (includ
 reference's swapped corrections, tracking.py:372-373).  ``phase_correlation_batch`` exposes
 the batched form used for stacks: every distinct image and template is transformed once.
 
-``template_matching`` (tracking.py:81-188) wraps cv2 / scikit-image in the reference; neither
-library ships here, so it raises ImportError exactly as the reference does without them.
+``template_matching`` (tracking.py:81-188) wraps cv2.matchTemplate(TM_CCOEFF_NORMED) /
+skimage.feature.match_template in the reference.  Here both back-end names run the same zero-mean
+normalised cross-correlation on the device (``b4d_template_match``): "opencv" z-scores the image as
+the reference does before calling cv2, "skimage" passes the raw float32 image.  Parity with the two
+libraries is unpinned (they are absent from the build image); the oracle follows their published
+definition (oracle/ncc_np.py).
 """
 from __future__ import annotations
 
@@ -54,10 +58,72 @@ def _as_float2d(a, *, name: str):
     return a
 
 
+def _check_pairs(images, tpl_src, tpl_frame, tpl_roi, pair_img, pair_tpl):
+    im, _, _ = D.to_device_f32(images, ndim=(3,))
+    if tpl_src is images:
+        ts = im
+    else:
+        ts, _, _ = D.to_device_f32(tpl_src, ndim=(3,))
+    if tuple(ts.shape[1:]) != tuple(im.shape[1:]):
+        raise ValueError("tpl_src frames must have the image shape.")
+    tf = np.ascontiguousarray(tpl_frame, dtype=np.int32).ravel()
+    tr = np.ascontiguousarray(tpl_roi, dtype=np.int32).reshape(-1, 4)
+    pi = np.ascontiguousarray(pair_img, dtype=np.int32).ravel()
+    pt = np.ascontiguousarray(pair_tpl, dtype=np.int32).ravel()
+    if tf.size != tr.shape[0] or pi.size != pt.size:
+        raise ValueError("index arrays have inconsistent lengths.")
+    return im, ts, tf, tr, pi, pt
+
+
+def _canvas(n: int) -> int:
+    p = 64
+    while p < n:
+        p *= 2
+    if p > 4096:
+        raise NotImplementedError(f"frame side {n} exceeds the largest native transform (4096).")
+    return p
+
+
+def _pad_frames(t, ny: int, nx: int):
+    torch = _ffi.require_gpu()
+    out = torch.zeros((t.shape[0], ny, nx), dtype=torch.float32, device=t.device)
+    out[:, :t.shape[1], :t.shape[2]] = t
+    return out
+
+
+def template_matching_batch(images, tpl_src, tpl_frame, tpl_roi, pair_img, pair_tpl, *, backend: str = "opencv",
+                            subpixel: bool = True, eps: float = 1e-9, return_peak_ij: bool = False):
+    """Batched NCC template matching; operands as in ``phase_correlation_batch``.  Returns (npairs, 4) float64 rows
+    (dy, dx, peak, snr) [, (npairs, 2) int32 arg-max indices in the (ny-h+1, nx-w+1) match map]."""
+    torch = _ffi.require_gpu()
+    if backend not in ("opencv", "skimage"):
+        raise ValueError("backend must be 'opencv' or 'skimage'.")
+    im, ts, tf, tr, pi, pt = _check_pairs(images, tpl_src, tpl_frame, tpl_roi, pair_img, pair_tpl)
+    nimg, H, W = (int(v) for v in im.shape)
+    # the "valid" correlation is linear: frames of any size ride a zero-padded power-of-two canvas exactly
+    ny, nx = _canvas(H), _canvas(W)
+    if (ny, nx) != (H, W):
+        same = ts is im
+        im = _pad_frames(im, ny, nx)
+        ts = im if same else _pad_frames(ts, ny, nx)
+    npairs = int(pi.size)
+    pl = _ffi.get_plan(ny, nx)
+    out = torch.empty((npairs, 4), dtype=torch.float64, device=im.device)
+    pij = torch.empty((npairs, 2), dtype=torch.int32, device=im.device)
+    as_p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    _ffi.check(_ffi.lib().b4d_template_match(
+        pl.handle, D.ptr(im), int(nimg), D.ptr(ts), int(ts.shape[0]), as_p(tf), as_p(tr), int(tf.size),
+        as_p(pi), as_p(pt), npairs, H, W, int(backend == "opencv"), int(bool(subpixel)), float(eps), D.ptr(out), D.ptr(pij),
+        _ffi.stream_ptr()))
+    res = out.cpu().numpy()
+    return (res, pij.cpu().numpy()) if return_peak_ij else res
+
+
 @_register("template")
 def template_matching(template, image, *, slices_yx=None, backend: Literal["opencv", "skimage"] = "opencv",
                       subpixel: bool = True, eps: float = 1e-9):
-    """NCC template matching (reference: tracking.py:81-188): third-party back-ends only."""
+    """Translation (dy, dx) by NCC template matching (reference: tracking.py:81-188) -> (dy, dx, peak_value, snr)."""
+    torch = _ffi.require_gpu()
     tpl = _as_float2d(template, name="template")
     img = _as_float2d(image, name="image")
     H, W = img.shape
@@ -65,12 +131,27 @@ def template_matching(template, image, *, slices_yx=None, backend: Literal["open
     if h > H or w > W:
         raise ValueError(f"template shape {(h, w)} must fit inside image shape {(H, W)}")
     if slices_yx is None:
-        roi_slices((H, W), (h, w), center_yx=None, clip=False)
-    if backend == "opencv":
-        raise ImportError("backend='opencv' requires opencv-python (cv2).")
-    if backend == "skimage":
-        raise ImportError("backend='skimage' requires scikit-image.")
-    raise ValueError("backend must be 'opencv' or 'skimage'.")
+        slices_yx = roi_slices((H, W), (h, w), center_yx=None, clip=False)
+    sy, sx = slices_yx
+    if backend not in ("opencv", "skimage"):
+        raise ValueError("backend must be 'opencv' or 'skimage'.")
+    # the kernels take the template as a ROI of a frame: put it at its reference position (or, if that position is not
+    # inside the frame, at the origin -- only the ROI statistics and the reference centre enter the result)
+    y0, x0 = int(sy.start), int(sx.start)
+    inside = 0 <= y0 and y0 + h <= H and 0 <= x0 and x0 + w <= W and (sy.stop - sy.start, sx.stop - sx.start) == (h, w)
+    py, px = (y0, x0) if inside else (0, 0)
+    timg, _, _ = D.to_device_f32(img[None], ndim=(3,))
+    ttpl, _, _ = D.to_device_f32(tpl, ndim=(2,))
+    canvas = torch.zeros((1, H, W), dtype=torch.float32, device=timg.device)
+    canvas[0, py:py + h, px:px + w] = ttpl
+    r = template_matching_batch(timg, canvas, [0], [[py, py + h, px, px + w]], [0], [0], backend=backend, subpixel=subpixel,
+                                eps=eps)[0]
+    # centre-to-centre shift against the reference centre of slices_yx (tracking.py:142-143, 182-186)
+    yc = (sy.start + sy.stop - 1) / 2.0
+    xc = (sx.start + sx.stop - 1) / 2.0
+    dy = float(r[0]) + py + (h - 1) / 2.0 - yc
+    dx = float(r[1]) + px + (w - 1) / 2.0 - xc
+    return dy, dx, float(r[2]), float(r[3])
 
 
 def phase_correlation_batch(images, tpl_src, tpl_frame, tpl_roi, pair_img, pair_tpl, *, subpixel: bool = True,

@@ -99,6 +99,20 @@ int b4d_phase_correlation(b4d_plan* plan, const float* images, int nimg, const f
                           const int32_t* pair_tpl, int npairs, int subpixel, double eps, double* out,
                           int32_t* peak_ij, void* stream);
 
+/* signal/tracking.py:81-188 template_matching: zero-mean normalised cross-correlation of z-scored templates with
+ * full frames over the "valid" window positions (the arithmetic of cv2.matchTemplate(TM_CCOEFF_NORMED) /
+ * skimage.feature.match_template(pad_input=False), which the reference imports), first-occurrence arg-max, peak,
+ * snr = |peak| / (median |ncc| + eps), 3x3 Taylor step, centre-to-centre shift against each template's ROI.
+ * Same operands as b4d_phase_correlation, plus img_h x img_w: the extent of the images inside the plan's (ny, nx)
+ * power-of-two canvas (0 = the whole canvas; frames of other sizes are zero-padded by the caller, which is exact for
+ * the "valid" correlation).  zscore_image != 0: the image is z-scored as a whole ("opencv" path,
+ * tracking.py:157); 0: raw float32 image ("skimage" path, tracking.py:166).  out: DEVICE (npairs, 4) float64
+ * {dy, dx, peak, snr}; peak_ij: DEVICE (npairs, 2) int32 arg-max in the (ny-h+1, nx-w+1) map, or null.            */
+int b4d_template_match(b4d_plan* plan, const float* images, int nimg, const float* tpl_src, int ntplsrc,
+                       const int32_t* tpl_frame, const int32_t* tpl_roi, int ntpl, const int32_t* pair_img,
+                       const int32_t* pair_tpl, int npairs, int img_h, int img_w, int zscore_image, int subpixel, double eps,
+                       double* out, int32_t* peak_ij, void* stream);
+
 /* Temporal per-pixel statistics (io/rw.py:129-132 for the mean).
  * accumulate: sum_x += sum_t x, sum_xx += sum_t x^2 over `nframes` frames of npix pixels
  * (float64 accumulators, caller zero-initialises).  finalize: mean, var (ddof 0),

@@ -128,7 +128,9 @@ def test_errors_match_reference(gm):
     with pytest.raises(TypeError):
         gm.sharpness_stack_stats(img.tolist())
     with pytest.raises(ImportError):
-        gm.speckle_stack_stats(img[None], verbose=False)           # default tracker needs scikit-image, like the reference
+        gm.speckle_stack_stats(img[None], tracking_method="phase", tracking_backend="skimage", verbose=False)
+    with pytest.raises(ValueError):
+        gm.speckle_stack_stats(img[None], tracking_method="template", tracking_backend="internal", verbose=False)
     with pytest.warns(RuntimeWarning):
         out = gm.speckle_stats(img[:300, :300].copy(), metrics="stats", verbose=False)   # too small for tiles
     assert "tiles" not in out
@@ -189,3 +191,22 @@ def test_sta2_eigenvalues_vs_oracle(gm, shape):
     wv = M.eigenvalues(lr)
     assert g["eigenvalues"] == pytest.approx(wv["eigenvalues"], rel=1e-5)
     assert g["e1"] == pytest.approx(wv["e1"], rel=1e-5)
+
+
+def test_stack_stats_default_tracker_any_size(gm):
+    """speckle_stack_stats with the reference's DEFAULT tracker ("template" / "skimage", speckles.py:266-267) on frames
+    that are not a power of two (zero-padded canvas: exact for the "valid" NCC) against the oracle."""
+    from oracle import metrics_np as M
+
+    stack, sh = synth.shifted_stack(3, 200, seed=31, max_shift=6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = gm.speckle_stack_stats(stack, metrics=("stats",), tiles=False, roi_grain_factor=8.0, verbose=False)
+        ref = M.speckle_stack_stats(stack, metrics=("stats",), tiles=False, roi_grain_factor=8.0)
+    assert got["meta"]["tracking"]["method"] == "template" and got["meta"]["tracking"]["backend"] == "skimage"
+    assert got["meta"]["tracking"]["roi_size_yx"] == ref["meta"]["tracking"]["roi_size_yx"]
+    for blk in ("abs", "inc"):
+        for k in ("dx", "dy", "r", "std_dx", "std_dy", "std_r"):
+            np.testing.assert_allclose(got["temporal"][blk][k], ref["temporal"][blk][k], atol=5e-3)
+    np.testing.assert_allclose(got["temporal"]["abs"]["dy"], sh[:, 0], atol=0.25)
+    np.testing.assert_allclose(got["temporal"]["abs"]["dx"], sh[:, 1], atol=0.25)
