@@ -52,6 +52,151 @@ __global__ void __launch_bounds__(256) k_pm_pre(const void* __restrict__ xin, fl
     }
 }
 
+// Fused length-N transform of one row per workgroup when M = A * B splits into two small factors: the radix-P
+// butterfly + twiddle of step A, then DFT_M as DFT_A (over a, n2 = B a + b), the twiddle W_M^{b c} and DFT_B (over b,
+// k2 = c + A d), all in LDS; the two small DFTs are dense sums from LDS-resident tables (M (A + B) complex MACs per
+// sequence instead of the M^2 of the DFT-matrix product).  Output k = k1 + P (c + A d), optional pointwise filter,
+// conjugation and scale fused into the coalesced copy-out.  Safe in place.
+//   IN  0 complex rows | 1 real rows | 2 rows of the reflect-padded, max-normalised frame taken straight from the
+//       (h, w) frame (np.pad(..., "reflect") / max|frame|, filters.py:252-261: no padded copy in memory)
+//   OUT 0 complex rows | 1 clip(Re, -1, 1) * max|frame| cropped back to (h, w) (filters.py:266, 287-289)
+// grid (S), block FT, dynamic LDS (2 N + A + B) complex values.
+constexpr int FT = 1024;
+struct FusedIO {
+    const float* frame;   // IN 2 / OUT 1: the (h, w) frame read / written
+    float* crop;
+    const float* amax;    // max|frame| (device scalar)
+    int h, w, py, px, clip;
+};
+
+template <int P, int IN, int OUT>
+__global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, float2* __restrict__ out, const float2* __restrict__ twN,
+                                                 int A, int B, const float2* __restrict__ filt, int conj_io, float scale, FusedIO io) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    const int M = A * B, N = P * M;
+    float2* buf0 = sm;
+    float2* buf1 = sm + N;
+    float2* tabA = buf1 + N;
+    float2* tabB = tabA + A;
+    const size_t s = blockIdx.x;
+    for (int i = threadIdx.x; i < A; i += FT) tabA[i] = twN[(size_t)(N / A) * i];
+    for (int i = threadIdx.x; i < B; i += FT) tabB[i] = twN[(size_t)(N / B) * i];
+    float fsc = 1.f;
+    bool fok = true;
+    if (IN == 2 || OUT == 1) {
+        fsc = io.amax[0];
+        fok = isfinite(fsc) && fsc != 0.f;
+    }
+    // ---- radix-P butterflies over n1 (stride M) and the twiddle W_N^{n2 k1}
+    for (int n2 = threadIdx.x; n2 < M; n2 += FT) {
+        float2 v[P];
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+            const size_t i = s * (size_t)N + (size_t)M * n1 + n2;
+            if (IN == 2) {
+                int y = (int)s - io.py, x = M * n1 + n2 - io.px;
+                y = y < 0 ? -y : (y >= io.h ? 2 * io.h - 2 - y : y);
+                x = x < 0 ? -x : (x >= io.w ? 2 * io.w - 2 - x : x);
+                v[n1] = make_float2(fok ? io.frame[(size_t)y * io.w + x] / fsc : 0.f, 0.f);
+            } else if (IN == 1) {
+                v[n1] = make_float2(static_cast<const float*>(xin)[i], 0.f);
+            } else {
+                const float2 q = static_cast<const float2*>(xin)[i];
+                v[n1] = conj_io ? make_float2(q.x, -q.y) : q;
+            }
+        }
+        Dft<P>::run(v);
+#pragma unroll
+        for (int k1 = 0; k1 < P; ++k1) buf0[k1 * M + n2] = k1 == 0 ? v[0] : cmulf(v[k1], twN[n2 * k1]);
+    }
+    __syncthreads();
+    // ---- DFT_A over a for every (k1, b), four outputs c per item, then the twiddle W_M^{b c} = W_N^{P b c}
+    const int nCB = (A + 3) / 4;
+    for (int it = threadIdx.x; it < P * B * nCB; it += FT) {
+        const int b = it % B, r = it / B, c0 = (r % nCB) * 4, k1 = r / nCB;
+        float2 acc[4];
+        int idx[4], cj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[j] = make_float2(0.f, 0.f);
+            idx[j] = 0;
+            cj[j] = (c0 + j) % A;
+        }
+        const float2* src = buf0 + k1 * M + b;
+#pragma unroll 4
+        for (int a = 0; a < A; ++a) {
+            const float2 x = src[B * a];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 w = tabA[idx[j]];
+                acc[j].x = fmaf(x.x, w.x, fmaf(-x.y, w.y, acc[j].x));
+                acc[j].y = fmaf(x.x, w.y, fmaf(x.y, w.x, acc[j].y));
+                idx[j] += cj[j];
+                idx[j] -= idx[j] >= A ? A : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < A) buf1[k1 * M + (c0 + j) * B + b] = cmulf(acc[j], twN[(size_t)P * b * (c0 + j)]);
+    }
+    __syncthreads();
+    // ---- DFT_B over b for every (k1, c), four outputs d per item -> natural order k = k1 + P (c + A d) in buf0
+    const int nDB = (B + 3) / 4;
+    for (int it = threadIdx.x; it < P * A * nDB; it += FT) {
+        const int c = it % A, r = it / A, d0 = (r % nDB) * 4, k1 = r / nDB;
+        float2 acc[4];
+        int idx[4], dj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[j] = make_float2(0.f, 0.f);
+            idx[j] = 0;
+            dj[j] = (d0 + j) % B;
+        }
+        const float2* src = buf1 + k1 * M + c * B;
+#pragma unroll 4
+        for (int b = 0; b < B; ++b) {
+            const float2 x = src[b];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 w = tabB[idx[j]];
+                acc[j].x = fmaf(x.x, w.x, fmaf(-x.y, w.y, acc[j].x));
+                acc[j].y = fmaf(x.x, w.y, fmaf(x.y, w.x, acc[j].y));
+                idx[j] += dj[j];
+                idx[j] -= idx[j] >= B ? B : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (d0 + j < B) buf0[k1 + P * (c + A * (d0 + j))] = acc[j];
+    }
+    __syncthreads();
+    if (OUT == 1) {
+        const int y = (int)s - io.py;
+        if (y < 0 || y >= io.h) return;
+        for (int x = threadIdx.x; x < io.w; x += FT) {
+            float v = buf0[x + io.px].x * scale;   // conj_io only flips the imaginary part
+            if (io.clip) v = fminf(fmaxf(v, -1.f), 1.f);
+            io.crop[(size_t)y * io.w + x] = fok ? v * fsc : 0.f;
+        }
+        return;
+    }
+    for (int k = threadIdx.x; k < N; k += FT) {
+        float2 v = buf0[k];
+        if (filt) v = cmulf(v, filt[s * (size_t)N + k]);
+        if (conj_io) v.y = -v.y;
+        out[s * (size_t)N + k] = make_float2(v.x * scale, v.y * scale);
+    }
+}
+
+// amax[0] = max of the `nparts` partial maxima (one wave)
+__global__ void __launch_bounds__(64) k_absmax_final(float* __restrict__ amax, int nparts) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 64) m = fmaxf(m, amax[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if (threadIdx.x == 0) amax[0] = m;
+}
+
 // step C: out[s*N + k1 + P k2] = z[(s*P + k1)*M + k2]  (* filt[same index], conj_out, * scale).  grid (ceil(N/256), S)
 __global__ void __launch_bounds__(256) k_pm_post(const float2* __restrict__ z, float2* __restrict__ out, int P, int M,
                                                  const float2* __restrict__ filt, int conj_out, float scale) {
@@ -84,13 +229,7 @@ __global__ void __launch_bounds__(256) k_transpose_c(const float2* __restrict__ 
 // np.pad(frame, ((py,py),(px,px)), mode="reflect") / scale  (filters.py:252-261); scale = max|frame| read from `amax`
 __global__ void __launch_bounds__(256) k_pad_reflect(const float* __restrict__ frame, int h, int w, int py, int px,
                                                      const float* __restrict__ amax, int nparts, float* __restrict__ out) {
-    __shared__ float s_scale;
-    if (threadIdx.x == 0) {
-        float m = 0.f;
-        for (int i = 0; i < nparts; ++i) m = fmaxf(m, amax[i]);
-        s_scale = m;
-    }
-    __syncthreads();
+    const float s_scale = amax[0];   // reduced by k_absmax_final
     const int H = h + 2 * py, W = w + 2 * px;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)H * W) return;
@@ -104,13 +243,7 @@ __global__ void __launch_bounds__(256) k_pad_reflect(const float* __restrict__ f
 // restored = clip(Re(z), -1, 1) * scale, cropped back to (h, w)  (filters.py:266, 287-289)
 __global__ void __launch_bounds__(256) k_crop_out(const float2* __restrict__ z, int h, int w, int py, int px,
                                                   const float* __restrict__ amax, int nparts, int clip, float* __restrict__ out) {
-    __shared__ float s_scale;
-    if (threadIdx.x == 0) {
-        float m = 0.f;
-        for (int i = 0; i < nparts; ++i) m = fmaxf(m, amax[i]);
-        s_scale = m;
-    }
-    __syncthreads();
+    const float s_scale = amax[0];
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)h * w) return;
     const int y = (int)(e / w), x = (int)(e % w), W = w + 2 * px;
@@ -155,6 +288,7 @@ using namespace b4d;
 struct b4d_wiener {
     int h, w, py, px, H, W;      // frame, half kernel, padded sizes
     int Px, Mx, Py, My;          // H = Py*My, W = Px*Mx
+    int Ax = 0, Bx = 0, Ay = 0, By = 0;  // Mx = Ax*Bx, My = Ay*By when the fused LDS transform applies (0: DFT-matrix product)
     float2* twx = nullptr;       // W-point twiddles
     float2* twy = nullptr;
     float2* dmx = nullptr;       // Mx x Mx DFT matrix
@@ -174,6 +308,47 @@ static void split_pm(int n, int* P, int* M) {
     *M = n / p;
 }
 
+// M = A * B with the smallest A + B; fused LDS path when the two small DFTs are cheap and the row fits in LDS
+static void split_ab(int P, int M, int* A, int* B) {
+    int best = 1;
+    for (int f = 1; (long long)f * f <= M; ++f)
+        if (M % f == 0) best = f;
+    const int a = M / best, b = best;
+    const size_t lds = sizeof(float2) * (2 * (size_t)P * M + a + b);
+    if (a + b <= 128 && lds <= 150 * 1024) {
+        *A = a;
+        *B = b;
+    } else {
+        *A = *B = 0;
+    }
+}
+
+template <int P, int IN, int OUT>
+static int pm_fused_launch2(const void* x, float2* out, const float2* tw, int A, int B, int S, const float2* filt, int conj_io, float scale,
+                            const FusedIO& io, hipStream_t st) {
+    const size_t lds = sizeof(float2) * (2 * (size_t)P * A * B + A + B);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_fused<P, IN, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       150 * 1024);
+    });
+    B4D_HIP(attr_err);
+    hipLaunchKernelGGL((k_pm_fused<P, IN, OUT>), dim3(S), dim3(FT), lds, st, x, out, tw, A, B, filt, conj_io, scale, io);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+// in_mode: 0 complex, 1 real, 2 reflect-padded frame (io.frame); out_mode: 0 complex, 1 cropped real (io.crop)
+template <int P>
+static int pm_fused_launch(const void* x, int in_mode, int out_mode, float2* out, const float2* tw, int A, int B, int S, const float2* filt,
+                           int conj_io, float scale, const FusedIO& io, hipStream_t st) {
+    if (out_mode == 1) return pm_fused_launch2<P, 0, 1>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
+    if (in_mode == 2) return pm_fused_launch2<P, 2, 0>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
+    if (in_mode == 1) return pm_fused_launch2<P, 1, 0>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
+    return pm_fused_launch2<P, 0, 0>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
+}
+
 template <int P>
 static int pm_pre_launch(const void* x, bool real_in, float2* y, const float2* tw, int M, int S, int conj_in, hipStream_t st) {
     const dim3 grid((M + 255) / 256, S);
@@ -188,8 +363,21 @@ static int pm_pre_launch(const void* x, bool real_in, float2* y, const float2* t
 // S sequences of length N = P*M, contiguous: out = DFT(in) (forward) or conj(DFT(conj(in))) * scale (inverse);
 // tmp holds S*N complex values; optional pointwise multiplier applied to the forward output.
 static int dft_rows(const void* in, bool real_in, float2* tmp, float2* tmp2, float2* out, int S, int P, int M, const float2* tw,
-                    const float2* dm, bool inverse, const float2* filt, float scale, hipStream_t st) {
+                    const float2* dm, bool inverse, const float2* filt, float scale, hipStream_t st, int A = 0, int B = 0,
+                    const FusedIO* fio = nullptr, int in_mode = -1, int out_mode = 0) {
     int rc;
+    if (A > 0) {  // fused LDS transform (M = A * B)
+        const FusedIO io = fio ? *fio : FusedIO{};
+        const int im = in_mode >= 0 ? in_mode : (real_in ? 1 : 0);
+        switch (P) {
+            case 1: return pm_fused_launch<1>(in, im, out_mode, out, tw, A, B, S, filt, inverse, scale, io, st);
+            case 2: return pm_fused_launch<2>(in, im, out_mode, out, tw, A, B, S, filt, inverse, scale, io, st);
+            case 4: return pm_fused_launch<4>(in, im, out_mode, out, tw, A, B, S, filt, inverse, scale, io, st);
+            case 8: return pm_fused_launch<8>(in, im, out_mode, out, tw, A, B, S, filt, inverse, scale, io, st);
+            case 16: return pm_fused_launch<16>(in, im, out_mode, out, tw, A, B, S, filt, inverse, scale, io, st);
+            default: return fail(B4D_ESIZE, "unsupported radix");
+        }
+    }
     switch (P) {
         case 1: rc = pm_pre_launch<1>(in, real_in, tmp, tw, M, S, inverse, st); break;
         case 2: rc = pm_pre_launch<2>(in, real_in, tmp, tw, M, S, inverse, st); break;
@@ -216,10 +404,10 @@ static int transpose_c(const float2* in, float2* out, int rows, int cols, hipStr
 // forward 2-D DFT of a real (H, W) array -> TRANSPOSED spectrum (W, H), left in pl->a (b, c are scratch).
 // dft_rows needs in != tmp != tmp2 != out (its first and last steps are permutations).
 static int fft2_real_T(b4d_wiener* pl, const float* x, hipStream_t st) {
-    int rc = dft_rows(x, true, pl->a, pl->b, pl->c, pl->H, pl->Px, pl->Mx, pl->twx, pl->dmx, false, nullptr, 1.f, st);
+    int rc = dft_rows(x, true, pl->a, pl->b, pl->c, pl->H, pl->Px, pl->Mx, pl->twx, pl->dmx, false, nullptr, 1.f, st, pl->Ax, pl->Bx);
     if (rc) return rc;
     if ((rc = transpose_c(pl->c, pl->a, pl->H, pl->W, st))) return rc;
-    return dft_rows(pl->a, false, pl->b, pl->c, pl->a, pl->W, pl->Py, pl->My, pl->twy, pl->dmy, false, nullptr, 1.f, st);
+    return dft_rows(pl->a, false, pl->b, pl->c, pl->a, pl->W, pl->Py, pl->My, pl->twy, pl->dmy, false, nullptr, 1.f, st, pl->Ay, pl->By);
 }
 
 extern "C" {
@@ -247,14 +435,16 @@ int b4d_wiener_create(int h, int w, const float* psf_host, int ky, int kx, float
     p->W = w + 2 * p->px;
     split_pm(p->W, &p->Px, &p->Mx);
     split_pm(p->H, &p->Py, &p->My);
+    split_ab(p->Px, p->Mx, &p->Ax, &p->Bx);
+    split_ab(p->Py, p->My, &p->Ay, &p->By);
     if (p->Mx > 4200 || p->My > 4200) {
         b4d_wiener_destroy(p);
         return fail(B4D_ESIZE, "padded size " + std::to_string(p->H) + "x" + std::to_string(p->W) + " has an odd factor > 4200");
     }
     int rc = make_twiddles(p->W, &p->twx);
     if (rc == B4D_OK) rc = make_twiddles(p->H, &p->twy);
-    if (rc == B4D_OK) rc = make_dft_matrix(p->Mx, &p->dmx);
-    if (rc == B4D_OK) rc = make_dft_matrix(p->My, &p->dmy);
+    if (rc == B4D_OK && !p->Ax) rc = make_dft_matrix(p->Mx, &p->dmx);
+    if (rc == B4D_OK && !p->Ay) rc = make_dft_matrix(p->My, &p->dmy);
     const size_t n = (size_t)p->H * p->W;
     hipError_t e = hipSuccess;
     if (rc == B4D_OK) {
@@ -321,21 +511,34 @@ int b4d_wiener_apply(b4d_wiener* p, const float* frames, int batch, float* out, 
     for (int b = 0; b < batch; ++b) {
         const float* f = frames + b * fp;
         hipLaunchKernelGGL(k_nanabsmax, dim3(256), dim3(1024), 0, st, f, fp, p->amax);
-        hipLaunchKernelGGL(k_pad_reflect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, p->h, p->w, p->py, p->px, p->amax, 256,
-                           p->padded);
+        hipLaunchKernelGGL(k_absmax_final, dim3(1), dim3(64), 0, st, p->amax, 256);
         B4D_HIP(hipGetLastError());
-        // forward: rows (padded -> c), transpose (c -> a), columns + filter (a -> a), all in the transposed domain after that
-        int rc = dft_rows(p->padded, true, p->a, p->b, p->c, p->H, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st);
+        FusedIO io{f, out + b * fp, p->amax, p->h, p->w, p->py, p->px, clip};
+        int rc;
+        // forward: rows (frame -> c), transpose (c -> a), columns + filter (a -> a), all in the transposed domain after that
+        if (p->Ax) {  // reflect padding and normalisation folded into the row pass's loads
+            rc = dft_rows(nullptr, true, p->a, p->b, p->c, p->H, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st, p->Ax, p->Bx, &io, 2, 0);
+        } else {
+            hipLaunchKernelGGL(k_pad_reflect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, p->h, p->w, p->py, p->px, p->amax, 1,
+                               p->padded);
+            B4D_HIP(hipGetLastError());
+            rc = dft_rows(p->padded, true, p->a, p->b, p->c, p->H, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st);
+        }
         if (rc) return rc;
         if ((rc = transpose_c(p->c, p->a, p->H, p->W, st))) return rc;
-        if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, p->W, p->Py, p->My, p->twy, p->dmy, false, p->filt, 1.f, st))) return rc;
+        if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, p->W, p->Py, p->My, p->twy, p->dmy, false, p->filt, 1.f, st, p->Ay, p->By))) return rc;
         // inverse: columns (a -> a), transpose (a -> b), rows (b -> b) with the 1/(H W) factor
-        if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, p->W, p->Py, p->My, p->twy, p->dmy, true, nullptr, 1.f, st))) return rc;
+        if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, p->W, p->Py, p->My, p->twy, p->dmy, true, nullptr, 1.f, st, p->Ay, p->By))) return rc;
         if ((rc = transpose_c(p->a, p->b, p->W, p->H, st))) return rc;
-        if ((rc = dft_rows(p->b, false, p->c, p->a, p->b, p->H, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st))) return rc;
-        hipLaunchKernelGGL(k_crop_out, dim3((unsigned)((fp + 255) / 256)), dim3(256), 0, st, p->b, p->h, p->w, p->py, p->px, p->amax, 256,
-                           clip, out + b * fp);
-        B4D_HIP(hipGetLastError());
+        if (p->Ax) {  // clip, rescale and crop folded into the last pass's stores
+            if ((rc = dft_rows(p->b, false, p->c, p->a, p->b, p->H, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st, p->Ax, p->Bx, &io, 0, 1)))
+                return rc;
+        } else {
+            if ((rc = dft_rows(p->b, false, p->c, p->a, p->b, p->H, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st))) return rc;
+            hipLaunchKernelGGL(k_crop_out, dim3((unsigned)((fp + 255) / 256)), dim3(256), 0, st, p->b, p->h, p->w, p->py, p->px, p->amax, 1,
+                               clip, out + b * fp);
+            B4D_HIP(hipGetLastError());
+        }
     }
     return B4D_OK;
 }
