@@ -59,7 +59,11 @@ __global__ void __launch_bounds__(256) k_pm_pre(const void* __restrict__ xin, fl
 // conjugation and scale fused into the coalesced copy-out.  Safe in place.
 //   IN  0 complex rows | 1 real rows | 2 rows of the reflect-padded, max-normalised frame taken straight from the
 //       (h, w) frame (np.pad(..., "reflect") / max|frame|, filters.py:252-261: no padded copy in memory)
+//       3 as 2 for the row PAIR (2 s, 2 s + 1) packed as real + i imaginary part of one transform
+//       4 the Hermitian pair: half rows 2 s, 2 s + 1 (io.half values each) extended to Ga + i Gb (inverse pass)
 //   OUT 0 complex rows | 1 clip(Re, -1, 1) * max|frame| cropped back to (h, w) (filters.py:266, 287-289)
+//       2 the pair's half spectra Fa, Fb (k = 0 .. io.half - 1) unpacked to half rows 2 s, 2 s + 1
+//       3 as 1 for the pair: real part -> row 2 s, imaginary part -> row 2 s + 1
 // grid (S), block FT, dynamic LDS (2 N + A + B) complex values.
 constexpr int FT = 1024;
 struct FusedIO {
@@ -67,6 +71,7 @@ struct FusedIO {
     float* crop;
     const float* amax;    // max|frame| (device scalar)
     int h, w, py, px, clip;
+    int half, rows;       // pair modes: half-row length N/2 + 1 and the number of (padded) rows
 };
 
 template <int P, int IN, int OUT>
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, f
     for (int i = threadIdx.x; i < B; i += FT) tabB[i] = twN[(size_t)(N / B) * i];
     float fsc = 1.f;
     bool fok = true;
-    if (IN == 2 || OUT == 1) {
+    if (IN == 2 || IN == 3 || OUT == 1 || OUT == 3) {
         fsc = io.amax[0];
         fok = isfinite(fsc) && fsc != 0.f;
     }
@@ -93,7 +98,27 @@ __global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, f
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
             const size_t i = s * (size_t)N + (size_t)M * n1 + n2;
-            if (IN == 2) {
+            if (IN == 3) {
+                int x = M * n1 + n2 - io.px;
+                x = x < 0 ? -x : (x >= io.w ? 2 * io.w - 2 - x : x);
+                float q[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int row = 2 * (int)s + e;
+                    int y = row - io.py;
+                    y = y < 0 ? -y : (y >= io.h ? 2 * io.h - 2 - y : y);
+                    q[e] = (fok && row < io.rows) ? io.frame[(size_t)y * io.w + x] / fsc : 0.f;
+                }
+                v[n1] = make_float2(q[0], q[1]);
+            } else if (IN == 4) {
+                const int idx = M * n1 + n2, j = idx <= N / 2 ? idx : N - idx;
+                const float2* pa = static_cast<const float2*>(xin) + (size_t)(2 * s) * io.half;
+                const float2 fa = pa[j];
+                const float2 fb = (2 * (int)s + 1 < io.rows) ? pa[io.half + j] : make_float2(0.f, 0.f);
+                // Ga + i Gb, Hermitian-extended beyond N/2; then the inverse's input conjugation
+                const float2 z = idx <= N / 2 ? make_float2(fa.x - fb.y, fa.y + fb.x) : make_float2(fa.x + fb.y, fb.x - fa.y);
+                v[n1] = make_float2(z.x, -z.y);
+            } else if (IN == 2) {
                 int y = (int)s - io.py, x = M * n1 + n2 - io.px;
                 y = y < 0 ? -y : (y >= io.h ? 2 * io.h - 2 - y : y);
                 x = x < 0 ? -x : (x >= io.w ? 2 * io.w - 2 - x : x);
@@ -170,6 +195,30 @@ __global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, f
             if (d0 + j < B) buf0[k1 + P * (c + A * (d0 + j))] = acc[j];
     }
     __syncthreads();
+    if (OUT == 2) {
+        float2* oa = out + (size_t)(2 * s) * io.half;
+        const bool has_b = 2 * (int)s + 1 < io.rows;
+        for (int k = threadIdx.x; k < io.half; k += FT) {
+            const float2 z = buf0[k], w = buf0[k == 0 ? 0 : N - k];
+            oa[k] = make_float2(0.5f * (z.x + w.x), 0.5f * (z.y - w.y));
+            if (has_b) oa[io.half + k] = make_float2(0.5f * (z.y + w.y), 0.5f * (w.x - z.x));
+        }
+        return;
+    }
+    if (OUT == 3) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int y = 2 * (int)s + e - io.py;
+            if (y < 0 || y >= io.h || 2 * (int)s + e >= io.rows) continue;
+            for (int x = threadIdx.x; x < io.w; x += FT) {
+                const float2 z = buf0[x + io.px];
+                float v = (e == 0 ? z.x : -z.y) * scale;   // conj(buf0): real part row a, imaginary part row b
+                if (io.clip) v = fminf(fmaxf(v, -1.f), 1.f);
+                io.crop[(size_t)y * io.w + x] = fok ? v * fsc : 0.f;
+            }
+        }
+        return;
+    }
     if (OUT == 1) {
         const int y = (int)s - io.py;
         if (y < 0 || y >= io.h) return;
@@ -343,6 +392,8 @@ static int pm_fused_launch2(const void* x, float2* out, const float2* tw, int A,
 template <int P>
 static int pm_fused_launch(const void* x, int in_mode, int out_mode, float2* out, const float2* tw, int A, int B, int S, const float2* filt,
                            int conj_io, float scale, const FusedIO& io, hipStream_t st) {
+    if (in_mode == 3) return pm_fused_launch2<P, 3, 2>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
+    if (in_mode == 4) return pm_fused_launch2<P, 4, 3>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
     if (out_mode == 1) return pm_fused_launch2<P, 0, 1>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
     if (in_mode == 2) return pm_fused_launch2<P, 2, 0>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
     if (in_mode == 1) return pm_fused_launch2<P, 1, 0>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
@@ -513,8 +564,23 @@ int b4d_wiener_apply(b4d_wiener* p, const float* frames, int batch, float* out, 
         hipLaunchKernelGGL(k_nanabsmax, dim3(256), dim3(1024), 0, st, f, fp, p->amax);
         hipLaunchKernelGGL(k_absmax_final, dim3(1), dim3(64), 0, st, p->amax, 256);
         B4D_HIP(hipGetLastError());
-        FusedIO io{f, out + b * fp, p->amax, p->h, p->w, p->py, p->px, clip};
+        FusedIO io{f, out + b * fp, p->amax, p->h, p->w, p->py, p->px, clip, p->W / 2 + 1, p->H};
         int rc;
+        if (p->Ax && p->Ay) {
+            // real input: rows ride in pairs (a + i b) through one complex transform, only the W/2 + 1 independent
+            // columns go through the column passes (the filter of a real PSF is Hermitian), the inverse row pass
+            // rebuilds each pair from its two half rows
+            const int Wh = p->W / 2 + 1, Hp = (p->H + 1) / 2;
+            if ((rc = dft_rows(nullptr, true, p->a, p->b, p->c, Hp, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st, p->Ax, p->Bx, &io, 3, 0)))
+                return rc;
+            if ((rc = transpose_c(p->c, p->a, p->H, Wh, st))) return rc;
+            if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, Wh, p->Py, p->My, p->twy, p->dmy, false, p->filt, 1.f, st, p->Ay, p->By))) return rc;
+            if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, Wh, p->Py, p->My, p->twy, p->dmy, true, nullptr, 1.f, st, p->Ay, p->By))) return rc;
+            if ((rc = transpose_c(p->a, p->b, Wh, p->H, st))) return rc;
+            if ((rc = dft_rows(p->b, false, p->c, p->a, p->c, Hp, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st, p->Ax, p->Bx, &io, 4, 0)))
+                return rc;
+            continue;
+        }
         // forward: rows (frame -> c), transpose (c -> a), columns + filter (a -> a), all in the transposed domain after that
         if (p->Ax) {  // reflect padding and normalisation folded into the row pass's loads
             rc = dft_rows(nullptr, true, p->a, p->b, p->c, p->H, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st, p->Ax, p->Bx, &io, 2, 0);

@@ -18,7 +18,8 @@ def pp():
     return preprocessing
 
 
-@pytest.mark.parametrize("shape,sigma", [((60, 52), 1.5), ((64, 64), (1.0, 2.0)), ((100, 37), 0.7), ((512, 512), 1.5)])
+@pytest.mark.parametrize("shape,sigma", [((60, 52), 1.5), ((64, 64), (1.0, 2.0)), ((100, 37), 0.7), ((512, 512), 1.5),
+                                         ((70, 258), 0.7), ((258, 258), 0.7)])  # 262 = 2 * 131: DFT-matrix fallback
 @pytest.mark.parametrize("clip", [True, False])
 def test_wiener_vs_oracle(pp, shape, sigma, clip):
     from oracle import wiener_np as W
