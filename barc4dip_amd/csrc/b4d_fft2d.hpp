@@ -624,6 +624,8 @@ struct b4d_plan {
     float2* gbuf1 = nullptr;
     float2* gbuf2 = nullptr;
     float2* gbuf3 = nullptr;
+    // general lengths beyond the DFT-matrix range: both axes through the fused P * A * B row transform (b4d_wiener.hip)
+    bool large = false;
 };
 
 // b4d_general.hip
@@ -632,6 +634,13 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
                          unsigned flags, hipStream_t st);
 int general_fft2d(b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st);
 int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, hipStream_t st);
+int general_dft2(const b4d_plan* pl, const void* X, bool x_real, int batch, int conj, float2* tmp, float2* F, hipStream_t st);
+// b4d_wiener.hip: general-length 1-D engine (n = P * A * B, in-LDS mixed radix) and batched complex transpose
+namespace b4d {
+bool pm_fusable(int n);
+int pm_rows(const void* in, bool real_in, float2* out, int S, int n, const float2* tw, bool inverse, float scale, hipStream_t st);
+int transpose_batch(const float2* in, float2* out, int rows, int cols, int batch, hipStream_t st);
+}  // namespace b4d
 // b4d_track.hip: x[b] /= max|x[b]| for `batch` maps of n floats; scratch holds >= 256 * batch floats
 int normalise_by_absmax(float* x, size_t n, int batch, float* scratch, hipStream_t st);
 

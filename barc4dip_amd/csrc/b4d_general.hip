@@ -1,4 +1,5 @@
-// b4d_general.hip -- general-length 2-D transforms (any 2 <= ny, nx <= 512) as dense DFT-matrix products.
+// b4d_general.hip -- general-length 2-D transforms: any 2 <= ny, nx <= 512 as dense DFT-matrix products; larger frames
+// whose sides split as P * A * B through the fused in-LDS mixed-radix row transform of b4d_wiener.hip (plan->large).
 //
 // The aggregators of barc4dip evaluate every metric on 3x3 tiles or 9x9 sub-tiles (metrics/common.py:75-106,
 // 278-378): 170/171-pixel tiles at 512^2, 227/228 at 2048^2 -- sizes with large prime factors (19, 227).  For these
@@ -233,9 +234,21 @@ int make_dft_matrix(int n, float2** out) {
 static int dft2(const b4d_plan* pl, const void* X, bool x_real, int batch, int conj, float2* tmp, float2* F, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx;
     const long long fp = (long long)ny * nx;
+    if (pl->large) {  // rows, transpose, columns, transpose back (sizes beyond the O(n^3) DFT-matrix range)
+        int rc = pm_rows(X, x_real, F, batch * ny, nx, pl->tw_x, conj != 0, 1.f, st);
+        if (rc == B4D_OK) rc = transpose_batch(F, tmp, ny, nx, batch, st);
+        if (rc == B4D_OK) rc = pm_rows(tmp, false, tmp, batch * nx, ny, pl->tw_y, conj != 0, 1.f, st);
+        if (rc == B4D_OK) rc = transpose_batch(tmp, F, nx, ny, batch, st);
+        return rc;
+    }
     int rc = b4d_cgemm(X, x_real, fp, 0, pl->wx, false, 0, conj, tmp, fp, ny, nx, nx, batch, st);
     if (rc) return rc;
     return b4d_cgemm(pl->wy, false, 0, conj, tmp, false, fp, 0, F, fp, ny, nx, ny, batch, st);
+}
+
+// exported: the 2-D transform of a general plan (F natural order; conj: conj(DFT(conj X)), no 1/(nx ny)); batch <= chunk
+int general_dft2(const b4d_plan* pl, const void* X, bool x_real, int batch, int conj, float2* tmp, float2* F, hipStream_t st) {
+    return dft2(pl, X, x_real, batch, conj, tmp, F, st);
 }
 
 int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* psd, float psd_scale, float* autocorr,
@@ -253,9 +266,7 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
         B4D_HIP(hipGetLastError());
         if (!autocorr) continue;
         // inverse of the REAL power spectrum: tmp = P * conj(Wx) lands in gbuf2, result in gbuf3
-        const long long fp = npix;
-        if ((rc = b4d_cgemm(P, true, fp, 0, pl->wx, false, 0, 1, pl->gbuf2, fp, ny, nx, nx, nb, st))) return rc;
-        if ((rc = b4d_cgemm(pl->wy, false, 0, 1, pl->gbuf2, false, fp, 0, pl->gbuf3, fp, ny, nx, ny, nb, st))) return rc;
+        if ((rc = dft2(pl, P, true, nb, 1, pl->gbuf2, pl->gbuf3, st))) return rc;
         hipLaunchKernelGGL(k_gen_real_out, dim3(eg.x, nb), dim3(256), 0, st, pl->gbuf3, ny, nx, autocorr + off,
                            1.0f / ((float)nx * (float)ny), flags);
         B4D_HIP(hipGetLastError());
@@ -277,7 +288,6 @@ int general_fft2d(b4d_plan* pl, const float* frames, int batch, float2* out, hip
 
 int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
-    const long long fp = npix;
     for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
         const int nb = std::min(pl->chunk, batch - b0);
         const size_t off = (size_t)b0 * npix;
@@ -286,8 +296,7 @@ int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float
         if ((rc = dft2(pl, b + off, true, nb, 0, pl->gbuf1, pl->gbuf3, st))) return rc;
         hipLaunchKernelGGL(k_gen_cross, dim3((npix + 255) / 256, nb), dim3(256), 0, st, pl->gbuf2, pl->gbuf3, npix, pl->gbuf2, flags);
         B4D_HIP(hipGetLastError());
-        if ((rc = b4d_cgemm(pl->gbuf2, false, fp, 0, pl->wx, false, 0, 1, pl->gbuf1, fp, ny, nx, nx, nb, st))) return rc;
-        if ((rc = b4d_cgemm(pl->wy, false, 0, 1, pl->gbuf1, false, fp, 0, pl->gbuf3, fp, ny, nx, ny, nb, st))) return rc;
+        if ((rc = dft2(pl, pl->gbuf2, false, nb, 1, pl->gbuf1, pl->gbuf3, st))) return rc;
         hipLaunchKernelGGL(k_gen_real_out, dim3((npix + 255) / 256, nb), dim3(256), 0, st, pl->gbuf3, ny, nx, corr + off,
                            1.0f / ((float)nx * (float)ny), 0u);
         B4D_HIP(hipGetLastError());

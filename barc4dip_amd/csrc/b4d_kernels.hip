@@ -13,14 +13,20 @@ extern "C" {
 
 const char* b4d_version(void) { return "b4d 0.1.0 (gfx950)"; }
 const char* b4d_last_error(void) { return last_error().c_str(); }
-int b4d_size_supported(int ny, int nx) { return (pow2_ok(ny) && pow2_ok(nx)) || (general_ok(ny) && general_ok(nx)); }
+static bool large_ok(int ny, int nx) {
+    return ny >= 2 && nx >= 2 && ny <= 8192 && nx <= 8192 && (size_t)ny * nx <= ((size_t)1 << 26) && pm_fusable(ny) && pm_fusable(nx);
+}
+int b4d_size_supported(int ny, int nx) {
+    return (pow2_ok(ny) && pow2_ok(nx)) || (general_ok(ny) && general_ok(nx)) || large_ok(ny, nx);
+}
 
 int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out) {
     if (!out) return fail(B4D_EINVAL, "out is null");
     *out = nullptr;
     if (!b4d_size_supported(ny, nx))
-        return fail(B4D_ESIZE, "plans need power-of-two ny, nx in [64, 4096] (FFT kernels) or any ny, nx in [2, 512] "
-                               "(DFT-matrix path); got " + std::to_string(ny) + "x" + std::to_string(nx));
+        return fail(B4D_ESIZE, "plans need power-of-two ny, nx in [64, 4096] (FFT kernels), any ny, nx in [2, 512] "
+                               "(DFT-matrix path) or sides up to 8192 that split as 2^k * A * B with A + B <= 128 (fused "
+                               "mixed-radix path); got " + std::to_string(ny) + "x" + std::to_string(nx));
     if (chunk < 1) return fail(B4D_EINVAL, "chunk must be >= 1");
     b4d_plan* p = new b4d_plan();
     p->ny = ny;
@@ -28,8 +34,15 @@ int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out) {
     p->chunk = chunk;
     if (!(pow2_ok(ny) && pow2_ok(nx))) {  // general-length plan
         p->general = true;
-        int rc = make_dft_matrix(nx, &p->wx);
-        if (rc == B4D_OK) rc = make_dft_matrix(ny, &p->wy);
+        p->large = !(general_ok(ny) && general_ok(nx));
+        int rc = B4D_OK;
+        if (p->large) {
+            rc = make_twiddles(nx, &p->tw_x);
+            if (rc == B4D_OK) rc = make_twiddles(ny, &p->tw_y);
+        } else {
+            rc = make_dft_matrix(nx, &p->wx);
+            if (rc == B4D_OK) rc = make_dft_matrix(ny, &p->wy);
+        }
         if (rc != B4D_OK) {
             b4d_plan_destroy(p);
             return rc;

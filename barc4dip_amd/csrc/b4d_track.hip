@@ -374,6 +374,63 @@ __global__ void __launch_bounds__(256) k_ncc_map(NccArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------ general-length phase correlation
+// z-scored ROI of a source frame embedded in a zero (ny, nx) canvas (geometry/roi.py:175-222).  grid (ceil(npix/256), items)
+__global__ void __launch_bounds__(256) k_embed_roi(const float* __restrict__ frames, int ny, int nx, const RowSrc* __restrict__ srcs,
+                                                   float* __restrict__ canvas) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * nx) return;
+    const RowSrc sd = srcs[blockIdx.y];
+    const int y = e / nx, x = e % nx;
+    const bool in = y >= sd.y0 && y < sd.y1 && x >= sd.x0 && x < sd.x1;
+    canvas[(size_t)blockIdx.y * ny * nx + e] = in ? (frames[(size_t)sd.frame * ny * nx + e] - sd.mean) / sd.denom : 0.f;
+}
+
+// whitened cross-power spectra of `pairs` (image, template) spectrum pairs.  grid (ceil(npix/256), pairs)
+__global__ void __launch_bounds__(256) k_gen_cps(const float2* __restrict__ spec, const int* __restrict__ ia, const int* __restrict__ ib,
+                                                 int npix, float eps, float2* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npix) return;
+    out[(size_t)blockIdx.y * npix + e] =
+        cross_power<true>(spec[(size_t)ia[blockIdx.y] * npix + e], spec[(size_t)ib[blockIdx.y] * npix + e], eps);
+}
+
+// mag = |Re(R)| * scale, fftshift-ed (signal/tracking.py:283-285; the imaginary part of the Hermitian inverse is rounding
+// noise), with per-workgroup first-occurrence arg-max partials over contiguous row-major chunks of the SHIFTED map.
+// grid (nblk, pairs), block 256
+__global__ void __launch_bounds__(256) k_gen_mag(const float2* __restrict__ R, int ny, int nx, float scale, float* __restrict__ mag,
+                                                 float* __restrict__ part_val, int* __restrict__ part_idx) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int n = ny * nx, per = (n + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * per, e1 = min(n, e0 + per);
+    const size_t fo = (size_t)blockIdx.y * n;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {   // e: index in the shifted map
+        const int y = e / nx, x = e % nx;
+        const int sy = (y + ny - ny / 2) % ny, sx = (x + nx - nx / 2) % nx;   // source (unshifted) position
+        const float v = fabsf(R[fo + (size_t)sy * nx + sx].x) * scale;
+        mag[fo + e] = v;
+        argmax_merge(bv, bi, v, e);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_down(bv, o, 64);
+        const int oi = __shfl_down(bi, o, 64);
+        argmax_merge(bv, bi, ov, oi);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sv[threadIdx.x >> 6] = bv;
+        si[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) argmax_merge(bv, bi, sv[k], si[k]);
+        part_val[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bv;
+        part_idx[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bi;
+    }
+}
+
 // ------------------------------------------------------------------------------------ |max| normalisation (xcorr2d, normalize="peak")
 __global__ void __launch_bounds__(1024) k_absmax_part(const float* __restrict__ x, size_t n, float* __restrict__ part) {
     __shared__ float sh[16];
@@ -518,6 +575,78 @@ int normalise_by_absmax(float* x, size_t n, int batch, float* scratch, hipStream
     return B4D_OK;
 }
 
+// phase correlation on a general-length plan (DFT-matrix or fused mixed-radix transforms): same steps as the
+// power-of-two path with full complex spectra
+static int general_phase_correlation(b4d_plan* pl, const float* images, int nimg, const float* tpl_src, const int32_t* tpl_frame,
+                                     const int32_t* tpl_roi, int ntpl, const int32_t* pair_img, const int32_t* pair_tpl, int npairs,
+                                     int subpixel, double eps, double* out, int32_t* peak_ij, hipStream_t st) {
+    const int ny = pl->ny, nx = pl->nx, npix = ny * nx, nsrc = nimg + ntpl, nblk = 256;
+    const int pc = std::max(1, std::min(npairs, pl->chunk));
+    size_t need = 0;
+    auto add = [&](size_t b) { need += ((b + 255) & ~(size_t)255) + 256; };
+    add(sizeof(float2) * (size_t)npix * nsrc);
+    add(sizeof(float) * (size_t)npix * pl->chunk);
+    add(sizeof(RowSrc) * nsrc);
+    add(sizeof(int) * 2 * (size_t)npairs);
+    add(sizeof(float) * (size_t)npix * pc);
+    add(sizeof(float) * (size_t)nblk * pc);
+    add(sizeof(int) * (size_t)nblk * pc);
+    Arena ar;
+    int rc = track_arena(pl, need, &ar);
+    if (rc) return rc;
+    float2* spec = ar.take<float2>((size_t)npix * nsrc);
+    float* canvas = ar.take<float>((size_t)npix * pl->chunk);
+    RowSrc* srcs = ar.take<RowSrc>(nsrc);
+    int* pidx = ar.take<int>(2 * (size_t)npairs);
+    float* mag = ar.take<float>((size_t)npix * pc);
+    float* pval = ar.take<float>((size_t)nblk * pc);
+    int* pind = ar.take<int>((size_t)nblk * pc);
+    std::vector<RowSrc> h(nsrc);
+    for (int i = 0; i < nimg; ++i) h[i] = RowSrc{i, 0, ny, 0, nx, 0.f, 1.f, 0};
+    for (int k = 0; k < ntpl; ++k)
+        h[nimg + k] = RowSrc{tpl_frame[k], tpl_roi[4 * k], tpl_roi[4 * k + 1], tpl_roi[4 * k + 2], tpl_roi[4 * k + 3], 0.f, 1.f, 0};
+    std::vector<int> hp(2 * (size_t)npairs);
+    for (int i = 0; i < npairs; ++i) {
+        hp[i] = pair_img[i];
+        hp[npairs + i] = nimg + pair_tpl[i];
+    }
+    B4D_HIP(hipMemcpyAsync(srcs, h.data(), sizeof(RowSrc) * nsrc, hipMemcpyHostToDevice, st));
+    B4D_HIP(hipMemcpyAsync(pidx, hp.data(), sizeof(int) * hp.size(), hipMemcpyHostToDevice, st));
+    B4D_HIP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_roi_stats, dim3(nimg), dim3(1024), 0, st, images, ny, nx, eps, srcs);
+    hipLaunchKernelGGL(k_roi_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, eps, srcs + nimg);
+    B4D_HIP(hipGetLastError());
+    const dim3 eg((npix + 255) / 256);
+    for (int s0 = 0; s0 < nsrc;) {   // spectra, once per distinct image / template; never straddle the two frame arrays
+        const int n = std::min(pl->chunk, (s0 < nimg ? nimg : nsrc) - s0);
+        hipLaunchKernelGGL(k_embed_roi, dim3(eg.x, n), dim3(256), 0, st, s0 < nimg ? images : tpl_src, ny, nx, srcs + s0, canvas);
+        B4D_HIP(hipGetLastError());
+        if ((rc = general_dft2(pl, canvas, true, n, 0, pl->gbuf1, spec + (size_t)s0 * npix, st))) return rc;
+        s0 += n;
+    }
+    for (int p0 = 0; p0 < npairs; p0 += pc) {
+        const int np = std::min(pc, npairs - p0);
+        hipLaunchKernelGGL(k_gen_cps, dim3(eg.x, np), dim3(256), 0, st, spec, pidx + p0, pidx + npairs + p0, npix, (float)eps, pl->gbuf2);
+        B4D_HIP(hipGetLastError());
+        if ((rc = general_dft2(pl, pl->gbuf2, false, np, 1, pl->gbuf1, pl->gbuf3, st))) return rc;
+        hipLaunchKernelGGL(k_gen_mag, dim3(nblk, np), dim3(256), 0, st, pl->gbuf3, ny, nx, 1.0f / ((float)nx * (float)ny), mag, pval, pind);
+        FinArgs fa{};
+        fa.mag = mag;
+        fa.part_val = pval;
+        fa.part_idx = pind;
+        fa.out = out + (size_t)p0 * 4;
+        fa.peak_ij = peak_ij ? peak_ij + (size_t)p0 * 2 : nullptr;
+        fa.ny = ny;
+        fa.nx = nx;
+        fa.nblk = nblk;
+        fa.subpixel = subpixel;
+        fa.eps = eps;
+        hipLaunchKernelGGL(k_track_fin, dim3(np), dim3(1024), 0, st, fa);
+        B4D_HIP(hipGetLastError());
+    }
+    return B4D_OK;
+}
+
 extern "C" {
 
 int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, void* stream) {
@@ -573,7 +702,6 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     if (!pl || !images || !tpl_src || !tpl_frame || !tpl_roi || !pair_img || !pair_tpl || !out)
         return fail(B4D_EINVAL, "null argument");
     if (nimg < 1 || ntplsrc < 1 || ntpl < 1 || npairs < 1) return fail(B4D_EINVAL, "counts must be >= 1");
-    if (pl->general) return fail(B4D_ESIZE, "phase correlation needs power-of-two ny, nx in [64, 4096]");
     const int ny = pl->ny, nx = pl->nx;
     for (int k = 0; k < ntpl; ++k) {
         const int32_t* r = tpl_roi + 4 * k;
@@ -585,6 +713,9 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         if (pair_img[i] < 0 || pair_img[i] >= nimg || pair_tpl[i] < 0 || pair_tpl[i] >= ntpl)
             return fail(B4D_EINVAL, "pair " + std::to_string(i) + ": index out of range");
     hipStream_t st = (hipStream_t)stream;
+    if (pl->general)
+        return general_phase_correlation(pl, images, nimg, tpl_src, tpl_frame, tpl_roi, ntpl, pair_img, pair_tpl, npairs, subpixel, eps,
+                                         out, peak_ij, st);
     const size_t fpix = (size_t)ny * nx, half = fpix / 2;
     const int pc = std::max(1, std::min(npairs, pl->chunk * 4));  // pairs per launch group
     const int nsrc = nimg + ntpl;

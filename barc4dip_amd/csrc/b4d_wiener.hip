@@ -264,6 +264,8 @@ __global__ void __launch_bounds__(256) k_pm_post(const float2* __restrict__ z, f
 __global__ void __launch_bounds__(256) k_transpose_c(const float2* __restrict__ in, float2* __restrict__ out, int rows, int cols) {
     __shared__ float2 t[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    in += (size_t)blockIdx.z * rows * cols;   // grid.z = batch of equally shaped matrices
+    out += (size_t)blockIdx.z * rows * cols;
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + threadIdx.x;
         if (r < rows && c < cols) t[i][threadIdx.x] = in[(size_t)r * cols + c];
@@ -446,11 +448,32 @@ static int dft_rows(const void* in, bool real_in, float2* tmp, float2* tmp2, flo
     return B4D_OK;
 }
 
-static int transpose_c(const float2* in, float2* out, int rows, int cols, hipStream_t st) {
-    hipLaunchKernelGGL(k_transpose_c, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, in, out, rows, cols);
+static int transpose_c(const float2* in, float2* out, int rows, int cols, hipStream_t st, int batch = 1) {
+    hipLaunchKernelGGL(k_transpose_c, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(32, 8), 0, st, in, out, rows, cols);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
+
+// ---- exported to b4d_general.hip: the fused row transform as a general-length 1-D engine
+namespace b4d {
+bool pm_fusable(int n) {
+    int P, M, A, B;
+    split_pm(n, &P, &M);
+    split_ab(P, M, &A, &B);
+    return A > 0;
+}
+// S contiguous sequences of length n: out = DFT(in), or conj(DFT(conj(in))) * scale when inverse; tw: n-point twiddles
+int pm_rows(const void* in, bool real_in, float2* out, int S, int n, const float2* tw, bool inverse, float scale, hipStream_t st) {
+    int P, M, A, B;
+    split_pm(n, &P, &M);
+    split_ab(P, M, &A, &B);
+    if (A <= 0) return fail(B4D_ESIZE, "length " + std::to_string(n) + " has no P * A * B split that fits the fused transform");
+    return dft_rows(in, real_in, nullptr, nullptr, out, S, P, M, tw, nullptr, inverse, nullptr, scale, st, A, B);
+}
+int transpose_batch(const float2* in, float2* out, int rows, int cols, int batch, hipStream_t st) {
+    return transpose_c(in, out, rows, cols, st, batch);
+}
+}  // namespace b4d
 
 // forward 2-D DFT of a real (H, W) array -> TRANSPOSED spectrum (W, H), left in pl->a (b, c are scratch).
 // dft_rows needs in != tmp != tmp2 != out (its first and last steps are permutations).

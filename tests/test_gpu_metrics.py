@@ -139,9 +139,22 @@ def test_errors_match_reference(gm):
 def test_stack_stats_vs_reference_golden(gm, golden):
     g = golden("stack.npz")
     stack, sh = synth.shifted_stack(5, 384, seed=1234, max_shift=12)
-    with pytest.raises(NotImplementedError):                       # tracking needs power-of-two frames: loud, no fallback
-        gm.speckle_stack_stats(stack, metrics=("amplitude", "grain", "stats"), tracking_method="phase",
-                               tracking_backend="internal", verbose=False)
+    # the reference's own run on this 384 x 384 stack (phase / internal tracker, general-length transforms here)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = gm.speckle_stack_stats(stack, metrics=("amplitude", "grain", "stats"), tiles=True, roi_grain_factor=24.0,
+                                     tracking_method="phase", tracking_backend="internal", verbose=False)
+    assert tuple(res["meta"]["tracking"]["roi_size_yx"]) == tuple(g["speckle/meta/roi_size_yx"])
+    assert tuple(res["meta"]["tracking"]["roi_step_yx"]) == tuple(g["speckle/meta/roi_step_yx"])
+    for blk in ("abs", "inc"):
+        for k in ("dx", "dy", "r", "std_dx", "std_dy", "std_r"):     # float32 series; sub-pixel Taylor step on float32 maps
+            np.testing.assert_allclose(res["temporal"][blk][k], g[f"speckle/temporal/{blk}/{k}"], atol=5e-3, err_msg=f"{blk}/{k}")
+    np.testing.assert_allclose(np.rint(res["temporal"]["abs"]["dy"]), sh[:, 0])
+    np.testing.assert_allclose(np.rint(res["temporal"]["abs"]["dx"]), sh[:, 1])
+    seen = []
+    res["full"]["grain"].pop("autocorr", None)
+    _walk("speckle", {"full": res["full"]}, g, 2e-5, seen)
+    assert len(seen) >= 8
     res2 = gm.sharpness_stack_stats(stack[:3], metrics=("gradient", "laplacian"), verbose=False)
     seen = []
     _walk("sharpness", {k: res2[k] for k in ("full", "tiles")}, g, 1e-9, seen)

@@ -112,9 +112,9 @@ def test_errors(gs):
     with pytest.raises(ValueError):
         gs.autocorr2d(np.zeros((4, 512, 512), dtype=np.float32))
     with pytest.raises(NotImplementedError):           # no CPU fallback for sizes without a plan
-        gs.psd2d(np.zeros((600, 600), dtype=np.float32))
+        gs.psd2d(np.zeros((1042, 1042), dtype=np.float32))             # 1042 = 2 * 521: no small-factor split
     with pytest.raises(NotImplementedError):
-        gs.autocorr2d(np.zeros((1000, 2048), dtype=np.float32))
+        gs.autocorr2d(np.zeros((1042, 2048), dtype=np.float32))
     with pytest.raises(NotImplementedError):
         gs.fft2d(np.zeros((512, 512), dtype=np.complex64))
 
@@ -222,6 +222,28 @@ def test_general_lengths_vs_oracle(gs, shape):
         assert nerr(gs.xcorr2d(img, b, **kw)[0], np.real(S.xcorr2d(r64, b.astype(np.float64), **kw)[0])) < TOL
     ac = gs.autocorr2d(img)[0]
     assert ac[shape[0] // 2, shape[1] // 2] == 1.0 and int(np.argmax(ac)) == (shape[0] // 2) * shape[1] + shape[1] // 2
+
+
+@pytest.mark.parametrize("shape", [(600, 600), (720, 1280), (1000, 2048), (513, 300), (2160, 2560)])
+def test_large_general_lengths_vs_oracle(gs, shape):
+    """Sides beyond the DFT-matrix range that split as 2^k * A * B (detector formats such as 2560 x 2160): fused
+    in-LDS mixed-radix transform, rows / transpose / columns.  Same 1e-5 bar as the power-of-two kernels."""
+    from oracle import signal_np as S
+
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    img = (rng.poisson(200.0, size=shape) + 5 * rng.random(shape)).astype(np.float32)
+    b = (np.roll(img, (2, -3), axis=(0, 1)) * 0.9 + rng.random(shape)).astype(np.float32)
+    r64 = img.astype(np.float64)
+    assert nerr(gs.fft2d(img)[0], S.fft2d(r64)[0]) < TOL
+    assert nerr(gs.psd2d(img, dx=0.5, dy=2.0)[0], S.psd2d(r64, dx=0.5, dy=2.0)[0]) < TOL
+    assert nerr(gs.autocorr2d(img)[0], S.autocorr2d(r64)[0]) < TOL
+    assert nerr(gs.xcorr2d(img, b)[0], np.real(S.xcorr2d(r64, b.astype(np.float64))[0])) < TOL
+    ac = gs.autocorr2d(img)[0]
+    assert ac[shape[0] // 2, shape[1] // 2] == 1.0 and int(np.argmax(ac)) == (shape[0] // 2) * shape[1] + shape[1] // 2
+    st = np.stack([img, b, img[::-1].copy()])
+    p3 = gs.psd2d_stack(st)
+    for i in range(3):
+        assert np.array_equal(p3[i], gs.psd2d(st[i])[0])
 
 
 @pytest.mark.parametrize("name", ["f64_24x32", "f32_32x16", "f64_17x23"])

@@ -209,3 +209,31 @@ def test_template_matching_batch_map_and_truth(gs):
         corr = N.match_template_ncc(stack[t], N.S.zscore2d(stack[0][y0:y1, x0:x1], 1e-9).astype(np.float32))
         assert tuple(pij[i]) == np.unravel_index(int(np.argmax(corr)), corr.shape)
         assert res[i, 2] == pytest.approx(float(corr.max()), abs=2e-4)
+
+
+@pytest.mark.parametrize("shape", [(200, 300), (171, 170), (600, 720)])
+def test_phase_correlation_general_sizes(gs, shape):
+    """Phase correlation on frames that are not a power of two (DFT-matrix / fused mixed-radix plans) against the
+    oracle: integer arg-max exact, sub-pixel shift / peak within the float32 bar of the power-of-two path."""
+    from oracle import signal_np as S
+
+    H, W = shape
+    rng = np.random.default_rng(H + W)
+    base = synth_frame(max(H, W), 5)[:H, :W]
+    for (dy, dx), (h, w) in (((3, -5), (61, 61)), ((-7, 11), (41, 81))):
+        fr = (np.roll(base, (dy, dx), axis=(0, 1)) + rng.normal(size=(H, W)) * 20).astype(np.float32)
+        y0, x0 = (H - h) // 2 - 10, (W - w) // 2 + 7
+        sl = (slice(y0, y0 + h), slice(x0, x0 + w))
+        want = S.phase_correlation(base[sl], fr, slices_yx=sl)
+        got = gs.phase_correlation(base[sl], fr, slices_yx=sl)
+        wi = S.phase_correlation(base[sl], fr, slices_yx=sl, subpixel=False)
+        gi = gs.phase_correlation(base[sl], fr, slices_yx=sl, subpixel=False)
+        assert (gi[0], gi[1]) == (wi[0], wi[1]) == (dy, dx)
+        assert got[0] == pytest.approx(want[0], abs=5e-3) and got[1] == pytest.approx(want[1], abs=5e-3)
+        assert got[2] == pytest.approx(want[2], rel=1e-3) and got[3] == pytest.approx(want[3], rel=2e-3)
+
+
+def synth_frame(n, seed):
+    from barc4dip_amd import synth
+
+    return synth.speckle_frame(n, seed)
