@@ -63,6 +63,7 @@ SIGNATURES = {
     "b4d_percentiles": (_i, [_vp, _i, _sz, _vp, _i, _vp, _vp]),
     "b4d_radial_profile": (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _vp]),
     "b4d_psd_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "b4d_richardson_lucy": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "b4d_wiener_create": (_i, [_i, _i, _vp, _i, _i, _f, C.POINTER(_vp)]),
     "b4d_wiener_apply": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "b4d_wiener_destroy": (_i, [_vp]),

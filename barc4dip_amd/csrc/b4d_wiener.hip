@@ -332,6 +332,66 @@ __global__ void __launch_bounds__(256) k_wiener_filter(const float2* __restrict_
     Wf[e] = make_float2(h.x / den, -h.y / den);
 }
 
+// ---- Richardson-Lucy (skimage.restoration.richardson_lucy as published; filters.py:270-277)
+// One step of the iteration on a (H, W) float32 image with a (ky, kx) kernel, "same" convolution, zero boundary:
+//   MODE 0: dst = image / (conv(src, psf) + 1e-12)          (0 where conv < feps when feps > 0)
+//   MODE 1: dst = dst * conv(src, flip(psf))
+// 64 x 32 output tile per workgroup, source tile + halo and the kernel staged in LDS.  grid (ceil(W/64), ceil(H/32))
+constexpr int RL_TX = 64, RL_TY = 32, RL_MAXK = 33;
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rl_step(const float* __restrict__ src, const float* __restrict__ image, float* __restrict__ dst,
+                                                 const float* __restrict__ psf, int H, int W, int ky, int kx, float feps) {
+    extern __shared__ float rl_sm[];
+    const int hy = ky / 2, hx = kx / 2, tw = RL_TX + 2 * hx, th = RL_TY + 2 * hy;
+    float* tile = rl_sm;              // th x tw
+    float* kk = rl_sm + th * tw;      // ky x kx, already oriented for a correlation-style inner loop
+    const int x0 = blockIdx.x * RL_TX, y0 = blockIdx.y * RL_TY;
+    for (int i = threadIdx.x; i < th * tw; i += 256) {
+        const int y = y0 - hy + i / tw, x = x0 - hx + i % tw;
+        tile[i] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f;
+    }
+    // conv(f, k)[y, x] = sum_{i, j} f[y + hy - i, x + hx - j] k[i, j] = sum_{p, q} tile[ty + p, tx + q] k[ky-1-p, kx-1-q];
+    // MODE 1 convolves with the flipped kernel: the two flips cancel
+    for (int i = threadIdx.x; i < ky * kx; i += 256) kk[i] = MODE == 0 ? psf[ky * kx - 1 - i] : psf[i];
+    __syncthreads();
+    const int tx = threadIdx.x % RL_TX, tyb = threadIdx.x / RL_TX;   // 4 rows of 64 lanes; each lane 8 output rows
+#pragma unroll 1
+    for (int r = 0; r < RL_TY / 4; ++r) {
+        const int ty = tyb + 4 * r, y = y0 + ty, x = x0 + tx;
+        if (y >= H || x >= W) continue;
+        float acc = 0.f;
+        for (int p = 0; p < ky; ++p) {
+            const float* row = tile + (ty + p) * tw + tx;
+            const float* krow = kk + p * kx;
+            for (int q = 0; q < kx; ++q) acc = fmaf(row[q], krow[q], acc);
+        }
+        const size_t o = (size_t)y * W + x;
+        if (MODE == 0) {
+            const float conv = acc + 1e-12f;
+            dst[o] = (feps > 0.f && conv < feps) ? 0.f : image[o] / conv;
+        } else {
+            dst[o] = dst[o] * acc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fill(float* __restrict__ x, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+// restored = clip(est, -1, 1) * scale cropped back to (h, w)
+__global__ void __launch_bounds__(256) k_rl_crop(const float* __restrict__ est, int h, int w, int py, int px, const float* __restrict__ amax,
+                                                 int clip, float* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)h * w) return;
+    const int y = (int)(e / w), x = (int)(e % w), W = w + 2 * px;
+    float v = est[(size_t)(y + py) * W + x + px];
+    if (clip) v = fminf(fmaxf(v, -1.f), 1.f);
+    const float sc = amax[0];
+    out[e] = (isfinite(sc) && sc != 0.f) ? v * sc : 0.f;
+}
+
 }  // namespace b4d
 
 using namespace b4d;
@@ -629,6 +689,44 @@ int b4d_wiener_apply(b4d_wiener* p, const float* frames, int batch, float* out, 
             B4D_HIP(hipGetLastError());
         }
     }
+    return B4D_OK;
+}
+
+int b4d_richardson_lucy(const float* frames, int batch, int h, int w, const float* psf_host, int ky, int kx, int num_iter,
+                        float filter_epsilon, int clip, float* out, void* stream) {
+    if (!frames || !out || !psf_host) return fail(B4D_EINVAL, "null argument");
+    if (batch < 1 || h < 2 || w < 2 || num_iter < 1) return fail(B4D_EINVAL, "batch, num_iter >= 1 and h, w >= 2 required");
+    if (ky < 1 || kx < 1 || !(ky & 1) || !(kx & 1) || ky > RL_MAXK || kx > RL_MAXK) return fail(B4D_EINVAL, "kernel sides must be odd and <= 33");
+    if (ky / 2 >= h || kx / 2 >= w) return fail(B4D_EINVAL, "kernel larger than the frame");
+    hipStream_t st = (hipStream_t)stream;
+    const int py = ky / 2, px = kx / 2, H = h + 2 * py, W = w + 2 * px;
+    const size_t n = (size_t)H * W, fp = (size_t)h * w;
+    void* ws = nullptr;
+    int rc = get_scratch(sizeof(float) * (3 * n + 256 + (size_t)ky * kx) + 1024, &ws);
+    if (rc) return rc;
+    float* work = static_cast<float*>(ws);
+    float* est = work + n;
+    float* rel = est + n;
+    float* amax = rel + n;
+    float* psf = amax + 256;
+    B4D_HIP(hipMemcpyAsync(psf, psf_host, sizeof(float) * ky * kx, hipMemcpyHostToDevice, st));
+    B4D_HIP(hipStreamSynchronize(st));   // psf_host is caller-owned
+    const size_t lds = sizeof(float) * ((size_t)(RL_TX + 2 * px) * (RL_TY + 2 * py) + (size_t)ky * kx);
+    const dim3 grid((W + RL_TX - 1) / RL_TX, (H + RL_TY - 1) / RL_TY);
+    for (int b = 0; b < batch; ++b) {
+        const float* f = frames + b * fp;
+        hipLaunchKernelGGL(k_nanabsmax, dim3(256), dim3(1024), 0, st, f, fp, amax);
+        hipLaunchKernelGGL(k_absmax_final, dim3(1), dim3(64), 0, st, amax, 256);
+        hipLaunchKernelGGL(k_pad_reflect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, h, w, py, px, amax, 1, work);
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, est, n, 0.5f);
+        for (int it = 0; it < num_iter; ++it) {
+            hipLaunchKernelGGL((k_rl_step<0>), grid, dim3(256), lds, st, est, work, rel, psf, H, W, ky, kx, filter_epsilon);
+            hipLaunchKernelGGL((k_rl_step<1>), grid, dim3(256), lds, st, rel, work, est, psf, H, W, ky, kx, 0.f);
+        }
+        hipLaunchKernelGGL(k_rl_crop, dim3((unsigned)((fp + 255) / 256)), dim3(256), 0, st, est, h, w, py, px, amax, clip, out + b * fp);
+        B4D_HIP(hipGetLastError());
+    }
+    B4D_HIP(hipStreamSynchronize(st));   // the shared scratch must outlive the kernels
     return B4D_OK;
 }
 

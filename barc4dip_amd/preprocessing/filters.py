@@ -4,8 +4,10 @@ Same signature, defaults and error behaviour as the reference (filters.py:17-191
 whole per-frame chain on the device (reflect pad, max-abs normalisation, Wiener-Hunt filter in the Fourier domain of
 the padded size, clip, rescale, crop: b4d_wiener_*).  The reference delegates the filter to
 ``skimage.restoration.wiener``; that library cannot be installed here, so the filter follows its published
-definition (Laplacian regulariser, `balance`) and parity is UNPINNED.  ``method="rl"`` / ``"uw"``
-(Richardson-Lucy, unsupervised Wiener: iterative / stochastic scikit-image algorithms) are not built.
+definition (Laplacian regulariser, `balance`) and parity is UNPINNED.  ``method="rl"`` runs
+Richardson-Lucy as published for ``skimage.restoration.richardson_lucy`` (``b4d_richardson_lucy``: two LDS-tiled
+direct convolutions per iteration, same padding / normalisation / crop; parity likewise unpinned).  ``method="uw"``
+(scikit-image's stochastic unsupervised Wiener-Hunt sampler) is not built.
 """
 from __future__ import annotations
 
@@ -113,14 +115,25 @@ def deconvolve_psf(images: np.ndarray, *, sigma: float | Sequence[float], method
         raise ValueError(f"Unsupported method: {method!r}. Use 'wiener', 'rl', or 'uw'.")
     if pad_mode != "reflect":
         raise ValueError("Only pad_mode='reflect' is supported (by design).")
-    if method != "wiener":
-        raise NotImplementedError(f"method={method!r} (scikit-image iterative deconvolution) is not built on the GPU path.")
+    if method == "uw":
+        raise NotImplementedError("method='uw' (scikit-image's stochastic unsupervised Wiener-Hunt sampler) is not built on the GPU path.")
     if balance is None:
         balance = 0.01
     stack = images if images.ndim == 3 else images[None]
     dev, _, _ = D.to_device_f32(stack, ndim=(3,))
-    plan = _wiener_plan(dev.shape[1], dev.shape[2], psf, balance)
-    out = plan.apply(dev, clip)
+    if method == "rl":
+        if num_iter < 1:
+            raise ValueError("num_iter must be >= 1 for method='rl'.")
+        import torch
+
+        out = torch.empty_like(dev)
+        p32 = np.ascontiguousarray(psf, dtype=np.float32)
+        _ffi.check(_ffi.lib().b4d_richardson_lucy(D.ptr(dev), int(dev.shape[0]), int(dev.shape[1]), int(dev.shape[2]),
+                                                  p32.ctypes.data_as(C.c_void_p), int(p32.shape[0]), int(p32.shape[1]), int(num_iter),
+                                                  float(filter_epsilon or 0.0), int(bool(clip)), D.ptr(out), _ffi.stream_ptr()))
+    else:
+        plan = _wiener_plan(dev.shape[1], dev.shape[2], psf, balance)
+        out = plan.apply(dev, clip)
     if images.ndim == 2:
         out = out[0]
     if verbose:

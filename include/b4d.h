@@ -182,6 +182,13 @@ int b4d_wiener_create(int h, int w, const float* psf, int ky, int kx, float bala
 int b4d_wiener_apply(b4d_wiener* plan, const float* frames, int batch, float* out, int clip, void* stream);
 int b4d_wiener_destroy(b4d_wiener* plan);
 
+/* preprocessing/filters.py:270-277 method="rl": Richardson-Lucy deconvolution as published for
+ * skimage.restoration.richardson_lucy (parity unpinned) with the reference's reflect padding by half the kernel,
+ * normalisation by max|frame| and crop (filters.py:252-261, 287-289).  frames/out: DEVICE (batch, h, w) float32;
+ * psf: HOST (ky, kx) float32, odd sides <= 33; filter_epsilon <= 0: none.  Synchronises the stream.            */
+int b4d_richardson_lucy(const float* frames, int batch, int h, int w, const float* psf, int ky, int kx, int num_iter,
+                        float filter_epsilon, int clip, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

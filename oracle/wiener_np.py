@@ -96,8 +96,31 @@ def wiener(image, psf, balance, clip=True):
     return out
 
 
-def deconv_one_frame(frame, psf, balance=0.01, clip=True):
-    """preprocessing/filters.py:233-289 (method='wiener')."""
+def richardson_lucy(image, psf, num_iter=50, clip=True, filter_epsilon=None):
+    """Richardson-Lucy as published for ``skimage.restoration.richardson_lucy`` (PARITY UNPINNED, see the module
+    header): start from a constant 0.5 image; ``conv = convolve(est, psf, "same") + 1e-12``;
+    ``rel = image / conv`` (0 where ``conv < filter_epsilon`` if given); ``est *= convolve(rel, flip(psf), "same")``;
+    clip to [-1, 1].  Input float32 stays float32; zero boundary."""
+    from scipy.signal import convolve
+
+    image = np.asarray(image, dtype=np.float32)
+    psf = np.asarray(psf, dtype=np.float32)
+    est = np.full(image.shape, 0.5, dtype=np.float32)
+    mirror = np.flip(psf)
+    for _ in range(int(num_iter)):
+        conv = convolve(est, psf, mode="same", method="direct") + np.float32(1e-12)
+        if filter_epsilon:
+            rel = np.where(conv < filter_epsilon, 0, image / conv).astype(np.float32)
+        else:
+            rel = image / conv
+        est = est * convolve(rel, mirror, mode="same", method="direct")
+    if clip:
+        est = np.clip(est, -1.0, 1.0)
+    return est.astype(np.float32, copy=False)
+
+
+def deconv_one_frame(frame, psf, balance=0.01, clip=True, method="wiener", num_iter=50, filter_epsilon=None):
+    """preprocessing/filters.py:233-289 (method='wiener' | 'rl')."""
     if frame.ndim != 2:
         raise ValueError("Internal error: frame must be 2D.")
     py, px = int(psf.shape[0] // 2), int(psf.shape[1] // 2)
@@ -106,28 +129,35 @@ def deconv_one_frame(frame, psf, balance=0.01, clip=True):
     if not np.isfinite(scale) or scale == 0.0:
         return np.zeros_like(padded, dtype=np.float32)[py:-py, px:-px]
     work = (padded / scale).astype(np.float32, copy=False)
-    restored = wiener(work, psf, float(balance), clip=bool(clip))
+    if method == "rl":
+        if num_iter < 1:
+            raise ValueError("num_iter must be >= 1 for method='rl'.")
+        restored = richardson_lucy(work, psf, num_iter=int(num_iter), clip=bool(clip), filter_epsilon=filter_epsilon)
+    else:
+        restored = wiener(work, psf, float(balance), clip=bool(clip))
     return (restored.astype(np.float32, copy=False) * scale)[py:-py, px:-px]
 
 
-def deconvolve_psf(images, *, sigma, method="wiener", clip=True, pad_mode="reflect", balance=None):
-    """preprocessing/filters.py:17-191 (method='wiener', serial)."""
+def deconvolve_psf(images, *, sigma, method="wiener", clip=True, pad_mode="reflect", balance=None, num_iter=50,
+                   filter_epsilon=None):
+    """preprocessing/filters.py:17-191 (method='wiener' | 'rl', serial)."""
     if not isinstance(images, np.ndarray):
         raise TypeError("deconvolve_psf expects a numpy.ndarray")
     if images.ndim not in (2, 3):
         raise ValueError(f"images must be 2D (H, W) or 3D (T, H, W); got ndim={images.ndim}")
     sy, sx = parse_sigma(sigma)
     psf = gaussian_psf(sy, sx, min_size=5)
-    if method != "wiener":
-        raise ValueError(f"oracle restates method='wiener' only (got {method!r}).")
+    if method not in ("wiener", "rl"):
+        raise ValueError(f"oracle restates method='wiener' and 'rl' only (got {method!r}).")
     if pad_mode != "reflect":
         raise ValueError("Only pad_mode='reflect' is supported (by design).")
     if balance is None:
         balance = 0.01
+    kw = dict(method=method, num_iter=num_iter, filter_epsilon=filter_epsilon)
     img = images.astype(np.float32, copy=False)
     if img.ndim == 2:
-        return deconv_one_frame(img, psf, balance, clip).astype(np.float32, copy=False)
+        return deconv_one_frame(img, psf, balance, clip, **kw).astype(np.float32, copy=False)
     out = np.empty_like(img, dtype=np.float32)
     for t in range(img.shape[0]):
-        out[t] = deconv_one_frame(img[t], psf, balance, clip)
+        out[t] = deconv_one_frame(img[t], psf, balance, clip, **kw)
     return out
