@@ -14,40 +14,65 @@
 namespace b4d {
 
 // ------------------------------------------------------------------------------------ ROI statistics
-// grid (items), block 1024: population mean / std of the ROI in float64 (two passes over the ROI),
-// stored as float like NumPy's float32 arithmetic does: z = (x - f32(mean)) / f32(std + eps).
-__global__ void __launch_bounds__(1024) k_roi_stats(const float* __restrict__ frames, int ny, int nx, double eps,
-                                                    RowSrc* __restrict__ srcs) {
-    __shared__ double sh[16];
-    __shared__ double s_mean;
-    RowSrc sd = srcs[blockIdx.x];
+// Population mean / std of every ROI in float64, stored as float like NumPy's float32 arithmetic does:
+// z = (x - f32(mean)) / f32(std + eps).  Two kernels so that a full-frame "ROI" is spread over the chip: shifted power
+// sums sum (x - x0), sum (x - x0)^2 (x0 = first ROI pixel: no cancellation) per slice, then one wave per item.
+constexpr int ROI_SPLIT = 32;
+// grid (ROI_SPLIT, items), block 256; part[item][slice] = {S1, S2}
+__global__ void __launch_bounds__(256) k_roi_part(const float* __restrict__ frames, int ny, int nx, const RowSrc* __restrict__ srcs,
+                                                  double* __restrict__ part) {
+    __shared__ double sh[8];
+    const RowSrc sd = srcs[blockIdx.y];
     const int h = sd.y1 - sd.y0, w = sd.x1 - sd.x0, n = h * w;
     const float* f = frames + (size_t)sd.frame * ny * nx;
-    auto reduce = [&](double v) -> double {
+    const double x0 = (double)f[(size_t)sd.y0 * nx + sd.x0];
+    const int per = (n + ROI_SPLIT - 1) / ROI_SPLIT, e0 = blockIdx.x * per, e1 = min(n, e0 + per);
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = e0 + threadIdx.x; i < e1; i += 256) {
+        const double d = (double)f[(size_t)(sd.y0 + i / w) * nx + sd.x0 + i % w] - x0;
+        a1 += d;
+        a2 = fma(d, d, a2);
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-        __syncthreads();
-        double s = 0.0;
-        for (int i = 0; i < 16; ++i) s += sh[i];
-        return s;
-    };
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) acc += (double)f[(size_t)(sd.y0 + i / w) * nx + sd.x0 + i % w];
-    const double mean = reduce(acc) / n;
-    if (threadIdx.x == 0) s_mean = mean;
+    for (int o = 32; o > 0; o >>= 1) {
+        a1 += __shfl_down(a1, o, 64);
+        a2 += __shfl_down(a2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = a1;
+        sh[4 + (threadIdx.x >> 6)] = a2;
+    }
     __syncthreads();
-    acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const double d = (double)f[(size_t)(sd.y0 + i / w) * nx + sd.x0 + i % w] - s_mean;
-        acc = fma(d, d, acc);
-    }
-    const double var = reduce(acc) / n;
     if (threadIdx.x == 0) {
-        srcs[blockIdx.x].mean = (float)s_mean;
-        srcs[blockIdx.x].denom = (float)(sqrt(var) + eps);
+        double* o = part + ((size_t)blockIdx.y * ROI_SPLIT + blockIdx.x) * 2;
+        o[0] = sh[0] + sh[1] + sh[2] + sh[3];
+        o[1] = sh[4] + sh[5] + sh[6] + sh[7];
     }
+}
+
+// grid (ceil(items / 64)), block 64: one lane per item
+__global__ void __launch_bounds__(64) k_roi_fin(const float* __restrict__ frames, int ny, int nx, double eps, int items,
+                                                const double* __restrict__ part, RowSrc* __restrict__ srcs) {
+    const int it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= items) return;
+    const RowSrc sd = srcs[it];
+    const double n = (double)(sd.y1 - sd.y0) * (sd.x1 - sd.x0);
+    const double x0 = (double)frames[((size_t)sd.frame * ny + sd.y0) * nx + sd.x0];
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < ROI_SPLIT; ++k) {
+        s1 += part[((size_t)it * ROI_SPLIT + k) * 2];
+        s2 += part[((size_t)it * ROI_SPLIT + k) * 2 + 1];
+    }
+    const double m = s1 / n, var = fmax(s2 / n - m * m, 0.0);
+    srcs[it].mean = (float)(x0 + m);
+    srcs[it].denom = (float)(sqrt(var) + eps);
+}
+
+static int roi_stats(const float* frames, int ny, int nx, double eps, RowSrc* srcs, int items, double* part, hipStream_t st) {
+    hipLaunchKernelGGL(k_roi_part, dim3(ROI_SPLIT, items), dim3(256), 0, st, frames, ny, nx, srcs, part);
+    hipLaunchKernelGGL(k_roi_fin, dim3((items + 63) / 64), dim3(64), 0, st, frames, ny, nx, eps, items, part, srcs);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
 }
 
 // ------------------------------------------------------------------------------------ product + inverse column pass
@@ -118,11 +143,15 @@ struct FinArgs {
     const int* geom;
     const float* med_src;
     size_t stride;
+    float* compact;         // optional (pairs, stride) scratch for the median's gathered bin (b4d_select.hpp)
 };
 
-// grid (pairs), block 1024
+// grid (pairs), block 1024, dynamic LDS FIN_LDS bytes
+constexpr int FIN_REP = 4;
+constexpr size_t FIN_LDS = sizeof(unsigned) * 2048 * FIN_REP;
 __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
-    __shared__ unsigned hist[2048];
+    constexpr int REP = FIN_REP;
+    extern __shared__ unsigned hist[];   // FIN_REP copies of the 2048-bin histogram
     __shared__ unsigned sh[4];
     __shared__ float sv[16];
     __shared__ int si[16];
@@ -160,14 +189,20 @@ __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
     __syncthreads();
     // ---- median of the magnitude map (np.median: mean of the two middle values for even counts,
     //      evaluated in float32 like NumPy does for a float32 array)
-    unsigned nl, ne;
+    unsigned nl, ne, cn = n;
+    const float* cx = msrc;
+    float* comp = p.compact ? p.compact + pair * stride : nullptr;
     float med;
     if (n & 1u) {
-        med = key2f(radix_select(msrc, n, n / 2, hist, sh, nl, ne));
+        med = key2f(radix_select<REP>(msrc, n, n / 2, hist, sh, nl, ne, comp));
     } else {
-        const unsigned ka = radix_select(msrc, n, n / 2 - 1, hist, sh, nl, ne);
+        const unsigned ka = radix_select<REP>(msrc, n, n / 2 - 1, hist, sh, nl, ne, comp, &cx, &cn);
         float a = key2f(ka), b = a;
-        if (nl + ne <= n / 2) b = key2f(next_larger_key(msrc, n, ka, hist));  // upper middle value = next larger element
+        if (nl + ne <= n / 2) {  // upper middle value = next larger element: in the gathered bin, else (rare) anywhere above it
+            unsigned kb = next_larger_key(cx, cn, ka, hist);
+            if (kb == 0xffffffffu && cx != msrc) kb = next_larger_key(msrc, n, ka, hist);
+            b = key2f(kb);
+        }
         med = __fmul_rn(__fadd_rn(a, b), 0.5f);
     }
     if (threadIdx.x != 0) return;
@@ -203,6 +238,18 @@ __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
         p.peak_ij[pair * 2] = mi;
         p.peak_ij[pair * 2 + 1] = mj;
     }
+}
+
+static int launch_track_fin(const FinArgs& fa, int pairs, hipStream_t st) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_fin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIN_LDS);
+    });
+    B4D_HIP(attr_err);
+    hipLaunchKernelGGL(k_track_fin, dim3(pairs), dim3(1024), FIN_LDS, st, fa);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
 }
 
 // ------------------------------------------------------------------------------------ NCC template matching
@@ -587,6 +634,7 @@ static int general_phase_correlation(b4d_plan* pl, const float* images, int nimg
     add(sizeof(float2) * (size_t)npix * nsrc);
     add(sizeof(float) * (size_t)npix * pl->chunk);
     add(sizeof(RowSrc) * nsrc);
+    add(sizeof(double) * 2 * ROI_SPLIT * nsrc);
     add(sizeof(int) * 2 * (size_t)npairs);
     add(sizeof(float) * (size_t)npix * pc);
     add(sizeof(float) * (size_t)nblk * pc);
@@ -597,6 +645,7 @@ static int general_phase_correlation(b4d_plan* pl, const float* images, int nimg
     float2* spec = ar.take<float2>((size_t)npix * nsrc);
     float* canvas = ar.take<float>((size_t)npix * pl->chunk);
     RowSrc* srcs = ar.take<RowSrc>(nsrc);
+    double* roi_part = ar.take<double>((size_t)2 * ROI_SPLIT * nsrc);
     int* pidx = ar.take<int>(2 * (size_t)npairs);
     float* mag = ar.take<float>((size_t)npix * pc);
     float* pval = ar.take<float>((size_t)nblk * pc);
@@ -613,9 +662,8 @@ static int general_phase_correlation(b4d_plan* pl, const float* images, int nimg
     B4D_HIP(hipMemcpyAsync(srcs, h.data(), sizeof(RowSrc) * nsrc, hipMemcpyHostToDevice, st));
     B4D_HIP(hipMemcpyAsync(pidx, hp.data(), sizeof(int) * hp.size(), hipMemcpyHostToDevice, st));
     B4D_HIP(hipStreamSynchronize(st));
-    hipLaunchKernelGGL(k_roi_stats, dim3(nimg), dim3(1024), 0, st, images, ny, nx, eps, srcs);
-    hipLaunchKernelGGL(k_roi_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, eps, srcs + nimg);
-    B4D_HIP(hipGetLastError());
+    if ((rc = roi_stats(images, ny, nx, eps, srcs, nimg, roi_part, st))) return rc;
+    if ((rc = roi_stats(tpl_src, ny, nx, eps, srcs + nimg, ntpl, roi_part + (size_t)2 * ROI_SPLIT * nimg, st))) return rc;
     const dim3 eg((npix + 255) / 256);
     for (int s0 = 0; s0 < nsrc;) {   // spectra, once per distinct image / template; never straddle the two frame arrays
         const int n = std::min(pl->chunk, (s0 < nimg ? nimg : nsrc) - s0);
@@ -641,7 +689,7 @@ static int general_phase_correlation(b4d_plan* pl, const float* images, int nimg
         fa.nblk = nblk;
         fa.subpixel = subpixel;
         fa.eps = eps;
-        hipLaunchKernelGGL(k_track_fin, dim3(np), dim3(1024), 0, st, fa);
+        if ((rc = launch_track_fin(fa, np, st))) return rc;
         B4D_HIP(hipGetLastError());
     }
     return B4D_OK;
@@ -725,10 +773,12 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     add(sizeof(float2) * (size_t)ny * nsrc);  // Nyquist column spectra
     add(sizeof(float) * (size_t)ny * nsrc);   // Nyquist bins after the row pass
     add(sizeof(RowSrc) * nsrc);
+    add(sizeof(double) * 2 * ROI_SPLIT * nsrc);
     add(sizeof(int) * 2 * (size_t)npairs);
     add(sizeof(float2) * half * pc);          // G
     add(sizeof(float) * (size_t)ny * pc);     // G of the Nyquist column
     add(sizeof(float) * fpix * pc);           // magnitude maps
+    add(sizeof(float) * fpix * pc);           // median scratch (gathered bin)
     add(sizeof(float) * 2048 * (size_t)pc);
     add(sizeof(int) * 2048 * (size_t)pc);
     Arena ar;
@@ -738,10 +788,12 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     float2* nyq = ar.take<float2>((size_t)ny * nsrc);
     float* nyq_rows = ar.take<float>((size_t)ny * nsrc);
     RowSrc* srcs = ar.take<RowSrc>(nsrc);
+    double* roi_part = ar.take<double>((size_t)2 * ROI_SPLIT * nsrc);
     int* pidx = ar.take<int>(2 * (size_t)npairs);
     float2* g = ar.take<float2>(half * pc);
     float* gnyq = ar.take<float>((size_t)ny * pc);
     float* mag = ar.take<float>(fpix * pc);
+    float* medws = ar.take<float>(fpix * pc);
     float* pval = ar.take<float>((size_t)2048 * pc);
     int* pind = ar.take<int>((size_t)2048 * pc);
 
@@ -758,9 +810,8 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     B4D_HIP(hipMemcpyAsync(srcs, h.data(), sizeof(RowSrc) * nsrc, hipMemcpyHostToDevice, st));
     B4D_HIP(hipMemcpyAsync(pidx, hp.data(), sizeof(int) * hp.size(), hipMemcpyHostToDevice, st));
     B4D_HIP(hipStreamSynchronize(st));  // h / hp are stack-owned
-    hipLaunchKernelGGL(k_roi_stats, dim3(nimg), dim3(1024), 0, st, images, ny, nx, eps, srcs);
-    hipLaunchKernelGGL(k_roi_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, eps, srcs + nimg);
-    B4D_HIP(hipGetLastError());
+    if ((rc = roi_stats(images, ny, nx, eps, srcs, nimg, roi_part, st))) return rc;
+    if ((rc = roi_stats(tpl_src, ny, nx, eps, srcs + nimg, ntpl, roi_part + (size_t)2 * ROI_SPLIT * nimg, st))) return rc;
     // ---- spectra (once per distinct image / template)
     const int fc = std::max(1, pl->chunk * 2);
     for (int i0 = 0; i0 < nimg; i0 += fc) {
@@ -795,6 +846,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         if ((rc = dispatch_c2r(pl, ra, np, st, C2R_MAG, nullptr, &nblk))) return rc;
         FinArgs fa{};
         fa.mag = mag;
+        fa.compact = medws;
         fa.part_val = pval;
         fa.part_idx = pind;
         fa.out = out + (size_t)p0 * 4;
@@ -804,7 +856,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         fa.nblk = nblk;
         fa.subpixel = subpixel;
         fa.eps = eps;
-        hipLaunchKernelGGL(k_track_fin, dim3(np), dim3(1024), 0, st, fa);
+        if ((rc = launch_track_fin(fa, np, st))) return rc;
         B4D_HIP(hipGetLastError());
     }
     return B4D_OK;
@@ -841,6 +893,7 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     add(sizeof(float2) * (size_t)ny * nsrc);
     add(sizeof(float) * (size_t)ny * nsrc);
     add(sizeof(RowSrc) * nsrc);
+    add(sizeof(double) * 2 * ROI_SPLIT * nsrc);
     add(sizeof(int) * 3 * (size_t)npairs);
     add(sizeof(double) * satn * nimg);
     add(sizeof(double) * satn * nimg);
@@ -858,6 +911,7 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     float2* nyq = ar.take<float2>((size_t)ny * nsrc);
     float* nyq_rows = ar.take<float>((size_t)ny * nsrc);
     RowSrc* srcs = ar.take<RowSrc>(nsrc);
+    double* roi_part = ar.take<double>((size_t)2 * ROI_SPLIT * nsrc);
     int* pidx = ar.take<int>(3 * (size_t)npairs);
     int* sidx = pidx + 2 * (size_t)npairs;
     double* sat1 = ar.take<double>(satn * nimg);
@@ -886,8 +940,8 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     B4D_HIP(hipMemcpyAsync(pidx, hp.data(), sizeof(int) * hp.size(), hipMemcpyHostToDevice, st));
     B4D_HIP(hipStreamSynchronize(st));
     // "opencv": the image is z-scored as a whole (tracking.py:157); "skimage": raw float32 image (tracking.py:166)
-    if (zscore_image) hipLaunchKernelGGL(k_roi_stats, dim3(nimg), dim3(1024), 0, st, images, ny, nx, eps, srcs);
-    hipLaunchKernelGGL(k_roi_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, eps, srcs + nimg);
+    if (zscore_image && (rc = roi_stats(images, ny, nx, eps, srcs, nimg, roi_part, st))) return rc;
+    if ((rc = roi_stats(tpl_src, ny, nx, eps, srcs + nimg, ntpl, roi_part + (size_t)2 * ROI_SPLIT * nimg, st))) return rc;
     hipLaunchKernelGGL(k_tpl_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, srcs + nimg, tstat);
     hipLaunchKernelGGL(k_sat_rows, dim3(ny, nimg), dim3(256), 0, st, images, ny, nx, srcs, sat1, sat2);
     hipLaunchKernelGGL(k_sat_cols, dim3((nx + 64) / 64, nimg), dim3(64), 0, st, ny, nx, sat1, sat2);
@@ -950,7 +1004,7 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
             fa.nblk = nblk;
             fa.subpixel = subpixel;
             fa.eps = eps;
-            hipLaunchKernelGGL(k_track_fin, dim3(np), dim3(1024), 0, st, fa);
+            if ((rc = launch_track_fin(fa, np, st))) return rc;
             B4D_HIP(hipGetLastError());
         }
     }
