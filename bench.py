@@ -96,7 +96,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # modulo: lets a 1-GPU box rehearse N > 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one process per GPU; RCCL ("nccl") carries device collectives (none on this data path: frames are
@@ -177,7 +177,7 @@ def main():
                                   "note": "SURVEY.md §8(d): B_pipe = 12N^2 + 40 N (N/2+1) per frame"},
             "outputs_ok": ok,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:     # the CPU leg is timed at N = 1 only (it would idle the other ranks)
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_frames)
         print(json.dumps(line), flush=True)
     plan.close()
