@@ -66,6 +66,19 @@ __global__ void __launch_bounds__(256) k_pm_pre(const void* __restrict__ xin, fl
 //       3 as 1 for the pair: real part -> row 2 s, imaginary part -> row 2 s + 1
 // grid (S), block FT, dynamic LDS (2 N + A + B) complex values.
 constexpr int FT = 1024;
+// acc += x * w (complex) in two packed FMAs
+__device__ __forceinline__ v2f cmac(v2f acc, v2f x, v2f w) {
+    v2f t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(x), "v"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(x), "v"(w), "v"(t));
+    return r;
+}
+// complex LDS words of one row transform: two row buffers + the small-DFT tables (full A x A / B x B matrices, padded to
+// multiples of 4 columns, when both factors are <= 32; otherwise the A + B roots of unity)
+__host__ __device__ inline size_t pm_lds_elems(int P, int A, int B) {
+    const size_t tabs = (A <= 32 && B <= 32) ? (size_t)A * ((A + 3) & ~3) + (size_t)B * ((B + 3) & ~3) : (size_t)A + B;
+    return 2 * (size_t)P * A * B + tabs;
+}
 struct FusedIO {
     const float* frame;   // IN 2 / OUT 1: the (h, w) frame read / written
     float* crop;
@@ -82,10 +95,23 @@ __global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, f
     float2* buf0 = sm;
     float2* buf1 = sm + N;
     float2* tabA = buf1 + N;
-    float2* tabB = tabA + A;
+    const bool blocked = A <= 32 && B <= 32;   // full small-DFT matrices in LDS, 4 x 2 register blocks, packed FMAs
+    const int Ap = (A + 3) & ~3, Bp = (B + 3) & ~3;
+    float2* tabB = tabA + (blocked ? A * Ap : A);
     const size_t s = blockIdx.x;
-    for (int i = threadIdx.x; i < A; i += FT) tabA[i] = twN[(size_t)(N / A) * i];
-    for (int i = threadIdx.x; i < B; i += FT) tabB[i] = twN[(size_t)(N / B) * i];
+    if (blocked) {   // tabA[a][c] = W_A^{a c} (c < A, else 0), tabB[b][d] = W_B^{b d}
+        for (int i = threadIdx.x; i < A * Ap; i += FT) {
+            const int a = i / Ap, c = i % Ap;
+            tabA[i] = c < A ? twN[(size_t)(N / A) * ((a * c) % A)] : make_float2(0.f, 0.f);
+        }
+        for (int i = threadIdx.x; i < B * Bp; i += FT) {
+            const int b = i / Bp, d = i % Bp;
+            tabB[i] = d < B ? twN[(size_t)(N / B) * ((b * d) % B)] : make_float2(0.f, 0.f);
+        }
+    } else {
+        for (int i = threadIdx.x; i < A; i += FT) tabA[i] = twN[(size_t)(N / A) * i];
+        for (int i = threadIdx.x; i < B; i += FT) tabB[i] = twN[(size_t)(N / B) * i];
+    }
     float fsc = 1.f;
     bool fok = true;
     if (IN == 2 || IN == 3 || OUT == 1 || OUT == 3) {
@@ -135,66 +161,147 @@ __global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, f
         for (int k1 = 0; k1 < P; ++k1) buf0[k1 * M + n2] = k1 == 0 ? v[0] : cmulf(v[k1], twN[n2 * k1]);
     }
     __syncthreads();
-    // ---- DFT_A over a for every (k1, b), four outputs c per item, then the twiddle W_M^{b c} = W_N^{P b c}
-    const int nCB = (A + 3) / 4;
-    for (int it = threadIdx.x; it < P * B * nCB; it += FT) {
-        const int b = it % B, r = it / B, c0 = (r % nCB) * 4, k1 = r / nCB;
-        float2 acc[4];
-        int idx[4], cj[4];
+    // ---- DFT_A over a (n2 = B a + b), then the twiddle W_M^{b c} = W_N^{P b c}
+#ifndef B4D_EXP_PM_SKIP23
+    if (blocked) {   // item = (k1, 4 outputs c, 2 columns b): per a two x reads and one 4-wide table row feed 8 complex MACs
+        const int nCB = Ap / 4, nBB = (B + 1) / 2;
+        for (int it = threadIdx.x; it < P * nCB * nBB; it += FT) {
+            const int bb = it % nBB, r = it / nBB, c0 = (r % nCB) * 4, k1 = r / nCB;
+            const int b0 = 2 * bb, b1 = min(b0 + 1, B - 1);
+            v2f acc[4][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[j] = make_float2(0.f, 0.f);
-            idx[j] = 0;
-            cj[j] = (c0 + j) % A;
-        }
-        const float2* src = buf0 + k1 * M + b;
-#pragma unroll 4
-        for (int a = 0; a < A; ++a) {
-            const float2 x = src[B * a];
+            for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = v2f{0.f, 0.f};
+            const float2* src = buf0 + k1 * M;
+            const float4* wrow = reinterpret_cast<const float4*>(tabA + c0);
+            auto step = [&](int a) {
+                const v2f x0 = to_v(src[B * a + b0]), x1 = to_v(src[B * a + b1]);
+                const float4 wa = wrow[a * (Ap / 2)], wb = wrow[a * (Ap / 2) + 1];
+                const v2f w[4] = {v2f{wa.x, wa.y}, v2f{wa.z, wa.w}, v2f{wb.x, wb.y}, v2f{wb.z, wb.w}};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][0] = cmac(acc[j][0], x0, w[j]);
+                    acc[j][1] = cmac(acc[j][1], x1, w[j]);
+                }
+            };
+            int a = 0;
+            for (; a + 3 < A; a += 4) {   // unrolled by hand: the loads of four steps are in flight together
+                step(a);
+                step(a + 1);
+                step(a + 2);
+                step(a + 3);
+            }
+            for (; a < A; ++a) step(a);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float2 w = tabA[idx[j]];
-                acc[j].x = fmaf(x.x, w.x, fmaf(-x.y, w.y, acc[j].x));
-                acc[j].y = fmaf(x.x, w.y, fmaf(x.y, w.x, acc[j].y));
-                idx[j] += cj[j];
-                idx[j] -= idx[j] >= A ? A : 0;
+                const int c = c0 + j;
+                if (c >= A) continue;
+                buf1[k1 * M + c * B + b0] = cmulf(to_f(acc[j][0]), twN[(size_t)P * b0 * c]);
+                if (b0 + 1 < B) buf1[k1 * M + c * B + b0 + 1] = cmulf(to_f(acc[j][1]), twN[(size_t)P * (b0 + 1) * c]);
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c0 + j < A) buf1[k1 * M + (c0 + j) * B + b] = cmulf(acc[j], twN[(size_t)P * b * (c0 + j)]);
-    }
-    __syncthreads();
-    // ---- DFT_B over b for every (k1, c), four outputs d per item -> natural order k = k1 + P (c + A d) in buf0
-    const int nDB = (B + 3) / 4;
-    for (int it = threadIdx.x; it < P * A * nDB; it += FT) {
-        const int c = it % A, r = it / A, d0 = (r % nDB) * 4, k1 = r / nDB;
-        float2 acc[4];
-        int idx[4], dj[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[j] = make_float2(0.f, 0.f);
-            idx[j] = 0;
-            dj[j] = (d0 + j) % B;
+    } else {
+        // ---- DFT_A over a for every (k1, b), four outputs c per item, then the twiddle W_M^{b c} = W_N^{P b c}
+        const int nCB = (A + 3) / 4;
+        for (int it = threadIdx.x; it < P * B * nCB; it += FT) {
+            const int b = it % B, r = it / B, c0 = (r % nCB) * 4, k1 = r / nCB;
+            float2 acc[4];
+            int idx[4], cj[4];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = make_float2(0.f, 0.f);
+                idx[j] = 0;
+                cj[j] = (c0 + j) % A;
+            }
+            const float2* src = buf0 + k1 * M + b;
+    #pragma unroll 4
+            for (int a = 0; a < A; ++a) {
+                const float2 x = src[B * a];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2 w = tabA[idx[j]];
+                    acc[j].x = fmaf(x.x, w.x, fmaf(-x.y, w.y, acc[j].x));
+                    acc[j].y = fmaf(x.x, w.y, fmaf(x.y, w.x, acc[j].y));
+                    idx[j] += cj[j];
+                    idx[j] -= idx[j] >= A ? A : 0;
+                }
+            }
+    #pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < A) buf1[k1 * M + (c0 + j) * B + b] = cmulf(acc[j], twN[(size_t)P * b * (c0 + j)]);
         }
-        const float2* src = buf1 + k1 * M + c * B;
-#pragma unroll 4
-        for (int b = 0; b < B; ++b) {
-            const float2 x = src[b];
+        }
+    __syncthreads();
+    // ---- DFT_B over b (k2 = c + A d) -> natural order k = k1 + P (c + A d) in buf0
+    if (blocked) {   // item = (k1, 2 rows c, 4 outputs d)
+        const int nCP = (A + 1) / 2, nDB = Bp / 4;
+        for (int it = threadIdx.x; it < P * nCP * nDB; it += FT) {
+            const int cp = it % nCP, r = it / nCP, d0 = (r % nDB) * 4, k1 = r / nDB;
+            const int c0 = 2 * cp, c1 = min(c0 + 1, A - 1);
+            v2f acc[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = v2f{0.f, 0.f};
+            const float2* s0 = buf1 + k1 * M + c0 * B;
+            const float2* s1 = buf1 + k1 * M + c1 * B;
+            const float4* wrow = reinterpret_cast<const float4*>(tabB + d0);
+            auto step = [&](int b) {
+                const v2f x0 = to_v(s0[b]), x1 = to_v(s1[b]);
+                const float4 wa = wrow[b * (Bp / 2)], wb = wrow[b * (Bp / 2) + 1];
+                const v2f w[4] = {v2f{wa.x, wa.y}, v2f{wa.z, wa.w}, v2f{wb.x, wb.y}, v2f{wb.z, wb.w}};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][0] = cmac(acc[j][0], x0, w[j]);
+                    acc[j][1] = cmac(acc[j][1], x1, w[j]);
+                }
+            };
+            int b = 0;
+            for (; b + 3 < B; b += 4) {
+                step(b);
+                step(b + 1);
+                step(b + 2);
+                step(b + 3);
+            }
+            for (; b < B; ++b) step(b);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float2 w = tabB[idx[j]];
-                acc[j].x = fmaf(x.x, w.x, fmaf(-x.y, w.y, acc[j].x));
-                acc[j].y = fmaf(x.x, w.y, fmaf(x.y, w.x, acc[j].y));
-                idx[j] += dj[j];
-                idx[j] -= idx[j] >= B ? B : 0;
+                const int d = d0 + j;
+                if (d >= B) continue;
+                buf0[k1 + P * (c0 + A * d)] = to_f(acc[j][0]);
+                if (c0 + 1 < A) buf0[k1 + P * (c0 + 1 + A * d)] = to_f(acc[j][1]);
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (d0 + j < B) buf0[k1 + P * (c + A * (d0 + j))] = acc[j];
-    }
+    } else {
+        // ---- DFT_B over b for every (k1, c), four outputs d per item -> natural order k = k1 + P (c + A d) in buf0
+        const int nDB = (B + 3) / 4;
+        for (int it = threadIdx.x; it < P * A * nDB; it += FT) {
+            const int c = it % A, r = it / A, d0 = (r % nDB) * 4, k1 = r / nDB;
+            float2 acc[4];
+            int idx[4], dj[4];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = make_float2(0.f, 0.f);
+                idx[j] = 0;
+                dj[j] = (d0 + j) % B;
+            }
+            const float2* src = buf1 + k1 * M + c * B;
+    #pragma unroll 4
+            for (int b = 0; b < B; ++b) {
+                const float2 x = src[b];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2 w = tabB[idx[j]];
+                    acc[j].x = fmaf(x.x, w.x, fmaf(-x.y, w.y, acc[j].x));
+                    acc[j].y = fmaf(x.x, w.y, fmaf(x.y, w.x, acc[j].y));
+                    idx[j] += dj[j];
+                    idx[j] -= idx[j] >= B ? B : 0;
+                }
+            }
+    #pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (d0 + j < B) buf0[k1 + P * (c + A * (d0 + j))] = acc[j];
+        }
+        }
     __syncthreads();
+#endif
     if (OUT == 2) {
         float2* oa = out + (size_t)(2 * s) * io.half;
         const bool has_b = 2 * (int)s + 1 < io.rows;
@@ -425,7 +532,7 @@ static void split_ab(int P, int M, int* A, int* B) {
     for (int f = 1; (long long)f * f <= M; ++f)
         if (M % f == 0) best = f;
     const int a = M / best, b = best;
-    const size_t lds = sizeof(float2) * (2 * (size_t)P * M + a + b);
+    const size_t lds = sizeof(float2) * pm_lds_elems(P, a, b);
     if (a + b <= 128 && lds <= 150 * 1024) {
         *A = a;
         *B = b;
@@ -437,7 +544,7 @@ static void split_ab(int P, int M, int* A, int* B) {
 template <int P, int IN, int OUT>
 static int pm_fused_launch2(const void* x, float2* out, const float2* tw, int A, int B, int S, const float2* filt, int conj_io, float scale,
                             const FusedIO& io, hipStream_t st) {
-    const size_t lds = sizeof(float2) * (2 * (size_t)P * A * B + A + B);
+    const size_t lds = sizeof(float2) * pm_lds_elems(P, A, B);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
