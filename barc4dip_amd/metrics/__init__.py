@@ -5,7 +5,8 @@ from . import kernels, sharpness, speckles, statistics, temporal
 from .sharpness import sharpness_stack_stats, sharpness_stats
 from .speckles import speckle_stack_stats, speckle_stats
 from .statistics import distribution_moments
+from . import sharded
 from .temporal import temporal_stats
 
 __all__ = ["sharpness", "sharpness_stats", "sharpness_stack_stats", "statistics", "speckles", "speckle_stats",
-           "speckle_stack_stats", "distribution_moments", "temporal", "temporal_stats", "kernels"]
+           "speckle_stack_stats", "distribution_moments", "temporal", "temporal_stats", "sharded", "kernels"]

@@ -29,7 +29,7 @@ def _reduce(sums, count, group=None):
     return sums, count
 
 
-def temporal_stats(local_stack, *, group=None, chunk: int = 64, return_tensors: bool = False):
+def temporal_stats(local_stack, *, group=None, chunk: int = 1024, return_tensors: bool = False):
     """mean / variance / contrast maps over ALL frames of all ranks.
 
     local_stack: this rank's frames (T_local, H, W), NumPy or ROCm tensor (float32 used).

@@ -53,3 +53,32 @@ def test_sharded_temporal_stats_equal_single_rank(tmp_path, world, total):
         np.testing.assert_allclose(g["con"], rc, rtol=1e-9)
     a, b = np.load(tmp_path / "r0.npz"), np.load(tmp_path / f"r{world - 1}.npz")
     assert np.array_equal(a["mean"], b["mean"]) and np.array_equal(a["var"], b["var"])   # every rank holds the same bits
+
+
+def _halo_worker(rank, world, port, total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from barc4dip_amd.metrics.sharded import exchange_tracking_frames, gather_series, shard_bounds
+
+    stack = synth.speckle_stack(total, 32, seed0=40)
+    t0, t1 = shard_bounds(total, world, rank)
+    f0, prev = exchange_tracking_frames(torch.from_numpy(stack[t0:t1]))
+    series = gather_series(np.arange(t0, t1, dtype=np.float32)[:, None] * np.ones((1, 3), np.float32))
+    np.savez(os.path.join(out_dir, f"h{rank}.npz"), f0=f0.numpy(), prev=prev.numpy(), t0=t0, series=series)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(2, 7), (3, 10)])
+def test_tracking_halo_and_frame0_broadcast(tmp_path, world, total):
+    """every rank ends up with global frame 0 and the frame just before its shard; the gathered series
+    is the global frame order on every rank."""
+    mp.spawn(_halo_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    stack = synth.speckle_stack(total, 32, seed0=40)
+    for r in range(world):
+        g = np.load(tmp_path / f"h{r}.npz")
+        t0 = int(g["t0"])
+        assert np.array_equal(g["f0"], stack[0])
+        assert np.array_equal(g["prev"], stack[max(t0 - 1, 0)])
+        assert np.array_equal(g["series"][:, 0], np.arange(total, dtype=np.float32))

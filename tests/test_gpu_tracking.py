@@ -237,3 +237,22 @@ def synth_frame(n, seed):
     from barc4dip_amd import synth
 
     return synth.speckle_frame(n, seed)
+
+
+def test_sharded_tracking_equals_single_rank(gs):
+    """Two frame shards tracked separately (frame 0 + one-frame halo handed over explicitly, as the collective of
+    metrics/sharded.py would deliver them) give exactly the numbers of one call over the whole stack."""
+    from barc4dip_amd import synth
+    from barc4dip_amd.metrics import sharded
+
+    stack, sh = synth.shifted_stack(6, 256, seed=5, max_shift=8)
+    rois = [(40, 101, 50, 111), (120, 181, 130, 191)]
+    full = sharded.track_stack_sharded(stack, rois, frame0=stack[0], prev=stack[0])
+    a = sharded.track_stack_sharded(stack[:2], rois, frame0=stack[0], prev=stack[0])
+    b = sharded.track_stack_sharded(stack[2:], rois, frame0=stack[0], prev=stack[1])
+    for k in full:
+        assert np.array_equal(np.concatenate([a[k], b[k]]), full[k]), k
+    big = [(30, 151, 40, 161)]                                       # a well-conditioned ROI also recovers the ground truth
+    tr = sharded.track_stack_sharded(stack, big, frame0=stack[0], prev=stack[0], subpixel=False)
+    assert np.array_equal(tr["dy_abs"][:, 0], sh[:, 0]) and np.array_equal(tr["dx_abs"][:, 0], sh[:, 1])
+    assert np.array_equal(tr["dy_inc"][1:, 0], np.diff(sh[:, 0])) and np.array_equal(tr["dx_inc"][1:, 0], np.diff(sh[:, 1]))
