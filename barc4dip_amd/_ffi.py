@@ -172,7 +172,9 @@ def default_chunk(ny: int, nx: int) -> int:
 def get_plan(ny: int, nx: int, chunk: int | None = None) -> Plan:
     import torch
 
-    key = (int(ny), int(nx), int(chunk or default_chunk(ny, nx)), torch.cuda.current_device())
+    # plans own device workspace: one per (device, stream), so that work queued on different streams never shares it
+    key = (int(ny), int(nx), int(chunk or default_chunk(ny, nx)), torch.cuda.current_device(),
+           int(torch.cuda.current_stream().cuda_stream))
     with _plans_lock:
         pl = _plans.get(key)
         if pl is None:

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/b4d.h"
@@ -16,6 +17,10 @@ inline int fail(int code, const std::string& msg) {
 }
 // lazily grown device scratch for second-stage reductions (b4d_stats.hip)
 int get_scratch(size_t bytes, void** out);
+// serialises the host side of every entry point that works in that shared scratch (re-entrant calls from several
+// host threads, e.g. joblib workers); device-side ordering comes from the stream: use ONE stream for these calls
+std::recursive_mutex& scratch_mutex();
+#define B4D_SCRATCH_LOCK() std::lock_guard<std::recursive_mutex> b4d_scratch_lk__(::b4d::scratch_mutex())
 
 #define B4D_HIP(call)                                                                      \
     do {                                                                                   \

@@ -432,6 +432,7 @@ __global__ void __launch_bounds__(1024) k_ritz(const double* __restrict__ partT,
 using namespace b4d;
 
 extern "C" int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int nx, double* out_host, int nout, void* stream) {
+    B4D_SCRATCH_LOCK();
     if (!frames || !out_host) return fail(B4D_EINVAL, "null argument");
     if (batch < 1 || ny < 1 || nx < 1 || nout < 1 || nout > 8) return fail(B4D_EINVAL, "batch, ny, nx >= 1 and 1 <= nout <= 8 required");
     hipStream_t st = (hipStream_t)stream;

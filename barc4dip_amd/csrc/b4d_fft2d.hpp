@@ -306,7 +306,16 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
             float pw[NC];
 #pragma unroll
             for (int k = 0; k < NC; ++k) pw[k] = v[k][j].x * v[k][j].x + v[k][j].y * v[k][j].y;
+#ifdef B4D_EXP_PSD_TILED
+            if (psd) {   // timing-only: same bytes, tile-contiguous addresses (DRAM page locality experiment)
+                float* pt = psd + ((size_t)ct * NY + ky) * 32 + NC * cpm;
+                *reinterpret_cast<float2*>(pt) = make_float2(pw[0] * s, pw[1] * s);
+                *reinterpret_cast<float2*>(pt + 16) = make_float2(pw[1] * s, pw[0] * s);
+            }
+            if (false) {
+#else
             if (psd) {
+#endif
                 const unsigned rd = (unsigned)((ky + NY / 2) & (NY - 1)) * nx, rm = (unsigned)((NY / 2 - ky) & (NY - 1)) * nx;
                 if (NC == 4)
                     *reinterpret_cast<float4*>(&psd[rd + nx / 2 + kx0]) =
@@ -607,6 +616,7 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
 using namespace b4d;
 
 struct b4d_plan {
+    std::recursive_mutex mu;   // host-side re-entrancy: one plan may be called from several host threads (one stream)
     int ny, nx, chunk, ct_w;
     float2* tw_x = nullptr;    // nx-point twiddles
     float2* tw_y = nullptr;    // ny-point twiddles
@@ -672,6 +682,7 @@ static inline int make_twiddles(int n, float2** out) {
     return B4D_OK;
 }
 
+#define B4D_PLAN_LOCK(pl) std::lock_guard<std::recursive_mutex> b4d_plan_lk__((pl)->mu)
 #define B4D_SIZE_SWITCH(n, CALL)        \
     switch (n) {                        \
         case 64: return CALL(64);       \

@@ -105,6 +105,8 @@ extern "C" void b4d_debug_set_diag(void* buf) { g_diag = static_cast<unsigned lo
 // after a final hipEventSynchronize -- used by bench.py to price each kernel inside its timed region.
 static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float* psd, float psd_scale,
                              float* autocorr, unsigned flags, hipStream_t st, float* kernel_ms) {
+    if (!pl) return fail(B4D_EINVAL, "plan is null");
+    B4D_PLAN_LOCK(pl);
     if (!pl || !frames) return fail(B4D_EINVAL, "null plan or input");
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
     if (!psd && !autocorr) return fail(B4D_EINVAL, "both outputs are null");
@@ -212,6 +214,7 @@ int b4d_autocorr2d(b4d_plan* pl, const float* frames, int batch, float* autocorr
 int b4d_fft2d(b4d_plan* pl, const float* frames, int batch, float* out_c64, void* stream) {
     if (!pl || !frames || !out_c64) return fail(B4D_EINVAL, "null argument");
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
+    B4D_PLAN_LOCK(pl);
     hipStream_t st = (hipStream_t)stream;
     if (pl->general) return general_fft2d(pl, frames, batch, reinterpret_cast<float2*>(out_c64), st);
     const size_t fpix = (size_t)pl->ny * pl->nx;

@@ -121,6 +121,7 @@ extern "C" int b4d_flat_field(const float* frames, int batch, size_t npix, const
 }
 
 extern "C" int b4d_repair_pixels(float* frames, int batch, int ny, int nx, const long long* idx, int nbad, void* stream) {
+    B4D_SCRATCH_LOCK();
     if (!frames || batch < 1 || ny < 1 || nx < 1 || nbad < 0 || (nbad > 0 && !idx)) return fail(B4D_EINVAL, "b4d_repair_pixels: bad argument");
     if (nbad == 0) return B4D_OK;
     hipStream_t st = (hipStream_t)stream;

@@ -24,6 +24,10 @@ namespace b4d {
 static std::mutex g_scratch_mu;
 static void* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
+std::recursive_mutex& scratch_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
 int get_scratch(size_t bytes, void** out) {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     if (bytes > g_scratch_bytes) {
@@ -564,6 +568,7 @@ int b4d_temporal_finalize(const double* sum_x, const double* sum_xx, double coun
 
 int b4d_moments(const float* frames, int batch, size_t npix, double eps, double saturation, double* out,
                 void* stream) {
+    B4D_SCRATCH_LOCK();
     if (!frames || !out) return fail(B4D_EINVAL, "null argument");
     if (batch < 1 || npix < 1) return fail(B4D_EINVAL, "batch and npix must be >= 1");
     if ((reinterpret_cast<uintptr_t>(frames) & 15) || (npix & 3))
@@ -586,6 +591,7 @@ int b4d_moments(const float* frames, int batch, size_t npix, double eps, double 
 }
 
 int b4d_sobel_laplace_stats(const float* frames, int batch, int ny, int nx, double* out, void* stream) {
+    B4D_SCRATCH_LOCK();
     if (!frames || !out) return fail(B4D_EINVAL, "null argument");
     if (batch < 1 || ny < 1 || nx < 1) return fail(B4D_EINVAL, "batch, ny, nx must be >= 1");
     const dim3 grid((nx + 63) / 64, (ny + 15) / 16, batch);
@@ -603,6 +609,7 @@ int b4d_sobel_laplace_stats(const float* frames, int batch, int ny, int nx, doub
 
 int b4d_percentiles(const float* frames, int batch, size_t npix, const double* q_host, int nq, double* out,
                     void* stream) {
+    B4D_SCRATCH_LOCK();
     if (!frames || !q_host || !out) return fail(B4D_EINVAL, "null argument");
     if (batch < 1 || npix < 1 || nq < 1 || nq > 16) return fail(B4D_EINVAL, "batch, npix >= 1 and 1 <= nq <= 16 required");
     if (npix > 0xffffffffull) return fail(B4D_EINVAL, "frame too large");
@@ -620,6 +627,7 @@ int b4d_percentiles(const float* frames, int batch, size_t npix, const double* q
 
 int b4d_radial_profile(const float* maps, int batch, int ny, int nx, int nr, int ntheta, double r_max, double* out,
                        void* stream) {
+    B4D_SCRATCH_LOCK();
     if (!maps || !out) return fail(B4D_EINVAL, "null argument");
     if (batch < 1 || ny < 2 || nx < 2 || nr < 2 || ntheta < 4 || !(r_max > 0)) return fail(B4D_EINVAL, "bad shape / sampling");
     hipLaunchKernelGGL(k_radial_profile, dim3(nr, batch), dim3(256), 0, (hipStream_t)stream, maps, ny, nx, nr, ntheta, r_max, out);
@@ -628,6 +636,7 @@ int b4d_radial_profile(const float* maps, int batch, int ny, int nx, int nr, int
 }
 
 int b4d_psd_stats(const float* psd, int batch, int ny, int nx, double* out, void* stream) {
+    B4D_SCRATCH_LOCK();
     if (!psd || !out) return fail(B4D_EINVAL, "null argument");
     if (batch < 1 || ny < 2 || nx < 2) return fail(B4D_EINVAL, "bad shape");
     hipStream_t st = (hipStream_t)stream;

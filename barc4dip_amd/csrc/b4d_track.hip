@@ -700,6 +700,7 @@ extern "C" {
 int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, void* stream) {
     if (!pl || !a || !b || !corr) return fail(B4D_EINVAL, "null argument");
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
+    B4D_PLAN_LOCK(pl);
     hipStream_t st = (hipStream_t)stream;
     if (pl->general) return general_xcorr(pl, a, b, batch, corr, flags, st);
     const size_t fpix = (size_t)pl->ny * pl->nx, half = fpix / 2, ny = pl->ny;
@@ -750,6 +751,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     if (!pl || !images || !tpl_src || !tpl_frame || !tpl_roi || !pair_img || !pair_tpl || !out)
         return fail(B4D_EINVAL, "null argument");
     if (nimg < 1 || ntplsrc < 1 || ntpl < 1 || npairs < 1) return fail(B4D_EINVAL, "counts must be >= 1");
+    B4D_PLAN_LOCK(pl);
     const int ny = pl->ny, nx = pl->nx;
     for (int k = 0; k < ntpl; ++k) {
         const int32_t* r = tpl_roi + 4 * k;
@@ -869,6 +871,7 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     if (!pl || !images || !tpl_src || !tpl_frame || !tpl_roi || !pair_img || !pair_tpl || !out)
         return fail(B4D_EINVAL, "null argument");
     if (nimg < 1 || ntplsrc < 1 || ntpl < 1 || npairs < 1) return fail(B4D_EINVAL, "counts must be >= 1");
+    B4D_PLAN_LOCK(pl);
     if (pl->general) return fail(B4D_ESIZE, "template matching needs a power-of-two canvas: ny, nx in [64, 4096]");
     const int ny = pl->ny, nx = pl->nx;
     if (img_h <= 0) img_h = ny;

@@ -504,6 +504,7 @@ __global__ void __launch_bounds__(256) k_rl_crop(const float* __restrict__ est, 
 using namespace b4d;
 
 struct b4d_wiener {
+    std::recursive_mutex mu;     // host-side re-entrancy (several host threads, one plan)
     int h, w, py, px, H, W;      // frame, half kernel, padded sizes
     int Px, Mx, Py, My;          // H = Py*My, W = Px*Mx
     int Ax = 0, Bx = 0, Ay = 0, By = 0;  // Mx = Ax*Bx, My = Ay*By when the fused LDS transform applies (0: DFT-matrix product)
@@ -744,6 +745,8 @@ int b4d_wiener_create(int h, int w, const float* psf_host, int ky, int kx, float
 }
 
 int b4d_wiener_apply(b4d_wiener* p, const float* frames, int batch, float* out, int clip, void* stream) {
+    if (!p) return fail(B4D_EINVAL, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(p->mu);
     if (!p || !frames || !out) return fail(B4D_EINVAL, "null argument");
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
     hipStream_t st = (hipStream_t)stream;
@@ -801,6 +804,7 @@ int b4d_wiener_apply(b4d_wiener* p, const float* frames, int batch, float* out, 
 
 int b4d_richardson_lucy(const float* frames, int batch, int h, int w, const float* psf_host, int ky, int kx, int num_iter,
                         float filter_epsilon, int clip, float* out, void* stream) {
+    B4D_SCRATCH_LOCK();
     if (!frames || !out || !psf_host) return fail(B4D_EINVAL, "null argument");
     if (batch < 1 || h < 2 || w < 2 || num_iter < 1) return fail(B4D_EINVAL, "batch, num_iter >= 1 and h, w >= 2 required");
     if (ky < 1 || kx < 1 || !(ky & 1) || !(kx & 1) || ky > RL_MAXK || kx > RL_MAXK) return fail(B4D_EINVAL, "kernel sides must be odd and <= 33");

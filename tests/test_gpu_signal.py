@@ -261,3 +261,24 @@ def test_golden_reference_vectors_small(gs, golden, name):
                 kw = dict(remove_mean=rm, standardize=st, normalize=nm)
                 assert nerr(gs.autocorr2d(a, **kw)[0], g[f"{name}/autocorr2d_{tag}"]) < TOL, tag
                 assert nerr(gs.xcorr2d(a, b, **kw)[0], np.real(g[f"{name}/xcorr2d_{tag}"])) < TOL, tag
+
+
+def test_thread_reentrancy(gs):
+    """The reference's stack functions call the per-frame entry points from joblib threads (speckles.py:323): the
+    C ABI must tolerate several host threads on one plan / the shared scratch.  8 threads x mixed calls == serial."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from barc4dip_amd import metrics as gm
+    from barc4dip_amd import synth
+
+    frames = [synth.speckle_frame(512, 300 + i) for i in range(8)]
+
+    def work(f):
+        return (gs.psd2d(f)[0], gs.autocorr2d(f)[0], gm.distribution_moments(f)["kurtosis"], gm.speckles.amplitude(f)["contrast"],
+                gs.phase_correlation(f[100:221, 100:221], f, slices_yx=(slice(100, 221), slice(100, 221)))[:2])
+
+    serial = [work(f) for f in frames]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        threaded = list(ex.map(work, frames))
+    for a, b in zip(serial, threaded):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
