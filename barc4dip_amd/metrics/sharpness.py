@@ -20,7 +20,8 @@ from ..signal import fft as _fft
 from . import kernels as K
 from .common import (apply_display_origin, choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
                      tile_spans, tiled_scalar_fields, tiles_meta)
-from .speckles import _dev2d, _fft_ok, _pad4, _pad_square_dev, _tile_batches, _widths_from_autocorr
+from .speckles import (_dev2d, _fft_ok, _pad4, _pad_square_batch, _pad_square_dev, _tile_batches, _widths_batch, _widths_from_autocorr,
+                       tiled_fields_batched)
 from .statistics import distribution_moments, moments_from_sums
 
 logger = logging.getLogger(__name__)
@@ -125,6 +126,25 @@ def inverse_autocorr_width(image, *, fraction: float = 1.0 / np.e,
     if verbose:
         logger.info("> inv_ac_width: sx=%.4g | sy=%.4g | seq=%.4g | r(lx/ly)=%.3g", out["sx"], out["sy"], out["seq"], out["r"])
     return out
+
+
+def _spectral_entropy_batch(stack) -> list[dict]:
+    """spectral_entropy() of every item of a (B, h, w) device stack (defaults; no padding, like the reference)."""
+    if not bool(stack.isfinite().all()):
+        raise ValueError("spectral_entropy requires all finite values.")
+    psd = _fft.psd2d_stack(stack, scale=False, return_tensors=True)
+    npx = int(stack.shape[1]) * int(stack.shape[2])
+    return [{"spectral_entropy": _entropy_from(row, npx, True)} for row in K.psd_stats_batch(psd)]
+
+
+def _inverse_autocorr_width_batch(stack, fraction: float = 1.0 / np.e, min_size_px: int = 32) -> list[dict]:
+    """inverse_autocorr_width() of every item of a (B, h, w) device stack."""
+    if min(int(stack.shape[1]), int(stack.shape[2])) < int(min_size_px):
+        raise ValueError(f"image too small for inverse autocorrelation width (min dimension < {int(min_size_px)}).")
+    ac = _corr.autocorr2d_stack(_pad_square_batch(stack), remove_mean=True, standardize=True, normalize="peak", return_tensors=True)
+    inv = lambda v: float(1.0 / v) if v != 0.0 else float("inf")  # noqa: E731
+    return [{"sx": inv(lx), "sy": inv(ly), "seq": inv(float(leq)), "r": float(lx / ly) if ly != 0.0 else float("inf")}
+            for lx, ly, leq in _widths_batch(ac, fraction)]
 
 
 def _sta2_device(stack, nout: int = 8) -> np.ndarray:
@@ -268,9 +288,9 @@ def sharpness_stats(image: np.ndarray, *, metrics: str | Sequence[str] = "all", 
         n, ys, xs = tile_spans(h, w, mode)
         if all(_fft_ok((y1 - y0, x1 - x0)) for y0, y1 in ys for x0, x1 in xs):
             if "spectral" in groups:
-                tiles_out["spectral"] = tiled_scalar_fields(t, tile_mode=mode, compute_fn=lambda v: {"spectral_entropy": spectral_entropy(v)})
+                tiles_out["spectral"] = tiled_fields_batched(t, mode, _spectral_entropy_batch)
             if "autocorrelation" in groups:
-                tiles_out["autocorrelation"] = tiled_scalar_fields(t, tile_mode=mode, compute_fn=inverse_autocorr_width)
+                tiles_out["autocorrelation"] = tiled_fields_batched(t, mode, _inverse_autocorr_width_batch)
         else:
             warnings.warn(f"tile statistics of {fft_groups} skipped: {tile_shape_px}-pixel tiles need a general-length "
                           "FFT plan (not built yet); full-frame values are unaffected.", RuntimeWarning, stacklevel=2)

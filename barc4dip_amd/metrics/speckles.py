@@ -115,6 +115,79 @@ def _bandwidth_from(stats_row) -> dict:
             "rf": float(sig_fx / sig_fy) if sig_fy != 0.0 else float("inf"), "spr": float(1.0 / den)}
 
 
+def _pad_square_batch(stack):
+    """pad_to_square(fill = mean of each item) for a (B, h, w) device stack (geometry/masks.py:11-57)."""
+    b, h, w = (int(v) for v in stack.shape)
+    if h == w:
+        return stack
+    n = max(h, w)
+    means = stack.double().mean(dim=(1, 2)).float()
+    out = means[:, None, None].expand(b, n, n).contiguous()
+    y0, x0 = (n - h) // 2, (n - w) // 2
+    out[:, y0:y0 + h, x0:x0 + w] = stack
+    return out
+
+
+def _widths_batch(ac, fraction: float):
+    """[(lx, ly, leq)] of a (B, n, n) device stack of autocorrelation maps (interpolated radial mean): one arg-max, one
+    gather of the two cuts and one radial-profile launch for the whole batch, then the 1-D crossing searches on the host."""
+    import torch
+
+    b, n_y, n_x = (int(v) for v in ac.shape)
+    flat = ac.reshape(b, -1).argmax(dim=1)
+    iy, ix = flat // n_x, flat % n_x
+    ar = torch.arange(b, device=ac.device)
+    y_cuts = ac[ar, :, ix].double().cpu().numpy()
+    x_cuts = ac[ar, iy, :].double().cpu().numpy()
+    iy, ix = iy.cpu().numpy(), ix.cpu().numpy()
+    rad, r = radial_profile_batch(ac)
+    if rad.shape[1] < 2 or r.size < 2:
+        raise ValueError("Radial profile is too short to estimate leq.")
+    dr = float(r[1] - r[0])
+    if dr <= 0:
+        raise ValueError("Invalid radial sampling (non-positive dr).")
+    out = []
+    for i in range(b):
+        ly, _ = width_at_fraction(y_cuts[i], fraction=fraction, center_index=int(iy[i]))
+        lx, _ = width_at_fraction(x_cuts[i], fraction=fraction, center_index=int(ix[i]))
+        dist, _ = distance_at_fraction_from_peak(rad[i], fraction=fraction, peak_index=0)
+        out.append((float(lx), float(ly), 2 * float(dist) * dr))
+    return out
+
+
+def _grain_batch(stack, fraction: float = 1.0 / np.e) -> list[dict]:
+    """lx, ly, leq, r of every item of a (B, h, w) device stack (the tile path of `grain`)."""
+    if min(int(stack.shape[1]), int(stack.shape[2])) < 128:
+        raise ValueError("image too small for speckle grain metrics (min dimension < 128).")
+    ac = _corr.autocorr2d_stack(_pad_square_batch(stack), remove_mean=True, standardize=False, normalize="peak", return_tensors=True)
+    return [{"lx": lx, "ly": ly, "leq": float(leq), "r": float(lx / ly) if ly != 0 else float("inf")}
+            for lx, ly, leq in _widths_batch(ac, fraction)]
+
+
+def _bandwidth_batch(stack) -> list[dict]:
+    """bandwidth() of every item of a (B, h, w) device stack."""
+    sq = _pad_square_batch(stack)
+    if not bool(sq.isfinite().all()):
+        raise ValueError("image mean is not finite.")
+    psd = _fft.psd2d_stack(sq, scale=True, return_tensors=True)
+    return [_bandwidth_from(row) for row in K.psd_stats_batch(psd)]
+
+
+def tiled_fields_batched(t, tile_mode: str, batch_fn) -> dict:
+    """{key: {"mean": (3, 3), "std": (3, 3)}} from batch_fn((B, th, tw) stack) -> [dict] evaluated once per tile shape
+    (the batched form of metrics/common.py:278-378)."""
+    n, batches = _tile_batches(t, tile_mode)
+    grids = None
+    for _, rcs, stack in batches:
+        vals = batch_fn(stack)
+        if grids is None:
+            grids = {k: np.empty((n, n), dtype=float) for k in vals[0]}
+        for (r, c), v in zip(rcs, vals):
+            for k in grids:
+                grids[k][r, c] = float(v[k])
+    return grids_to_fields(grids, n)
+
+
 # ------------------------------------------------------------------------------------------------ metric functions
 def grain(image, *, fraction: float = 1.0 / np.e, radial_method: Literal["binned", "interpolated"] = "interpolated",
           verbose: bool = False) -> dict:
@@ -262,13 +335,10 @@ def speckle_stats(image: np.ndarray, *, metrics: str | Sequence[str] = "all", ti
         n, ys, xs = tile_spans(h, w, mode)
         native = all(_fft_ok((y1 - y0, x1 - x0)) for y0, y1 in ys for x0, x1 in xs)
         if native:
-            from .common import tiled_scalar_fields
-
-            if "grain" in groups:
-                tiles_out["grain"] = tiled_scalar_fields(
-                    t, tile_mode=mode, compute_fn=lambda v: {k: float(x) for k, x in grain(v).items() if k in ("lx", "ly", "leq", "r")})
+            if "grain" in groups:      # all tiles of one shape per launch
+                tiles_out["grain"] = tiled_fields_batched(t, mode, _grain_batch)
             if "bandwidth" in groups:
-                tiles_out["bandwidth"] = tiled_scalar_fields(t, tile_mode=mode, compute_fn=bandwidth)
+                tiles_out["bandwidth"] = tiled_fields_batched(t, mode, _bandwidth_batch)
         else:
             warnings.warn(f"tile statistics of {fft_groups} skipped: {tile_shape_px}-pixel tiles need a general-length "
                           "FFT plan (not built yet); full-frame values are unaffected.", RuntimeWarning, stacklevel=2)

@@ -1,0 +1,23 @@
+"""dev: cProfile of speckle_stats / sharpness_stats on one 2048^2 frame (where does the host time go?)."""
+import cProfile
+import pstats
+import sys
+import warnings
+
+import torch
+
+sys.path.insert(0, ".")
+from barc4dip_amd import metrics as gm, synth  # noqa: E402
+
+warnings.simplefilter("ignore")
+img = synth.speckle_frame(2048, 1234)
+for fn in (gm.speckle_stats, gm.sharpness_stats):
+    fn(img, verbose=False)
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    fn(img, verbose=False)
+    torch.cuda.synchronize()
+    pr.disable()
+    print("=====", fn.__name__)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
