@@ -28,14 +28,15 @@ def to_device_f32(a, *, ndim: tuple[int, ...]):
             raise NotImplementedError("complex input is not supported by the HIP path (real frames only).")
         if a.ndim not in ndim:
             raise ValueError(f"expected ndim in {ndim}, got {a.ndim}")
-        src_dtype = np.float64 if a.dtype == torch.float64 else np.float32
+        src_dtype = np.float32 if a.dtype in (torch.float32, torch.float16, torch.bfloat16) else np.float64
         return a.to(device="cuda", dtype=torch.float32).contiguous(), True, src_dtype
     arr = np.asarray(a)
     if np.iscomplexobj(arr):
         raise NotImplementedError("complex input is not supported by the HIP path (real frames only).")
     if arr.ndim not in ndim:
         raise ValueError(f"expected ndim in {ndim}, got {arr.ndim}")
-    src_dtype = np.float64 if arr.dtype == np.float64 else np.float32
+    # NumPy's FFT promotes everything except float16 / float32 to double precision: outputs follow that dtype
+    src_dtype = np.float32 if arr.dtype in (np.float32, np.float16) else np.float64
     t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to("cuda", non_blocking=False)
     return t, False, src_dtype
 
@@ -47,3 +48,10 @@ def ptr(t) -> C.c_void_p:
 def to_host(t, dtype=None) -> np.ndarray:
     out = t.detach().cpu().numpy()
     return out.astype(dtype, copy=False) if dtype is not None else out
+
+
+def result_dtype(a):
+    """Real dtype the reference's NumPy pipeline would return for input `a`: float32 for float16 / float32 input,
+    float64 for everything else (integers, bool, float64) -- numpy.fft promotes those to double precision."""
+    name = str(getattr(a, "dtype", "float64")).replace("torch.", "")
+    return np.float32 if name in ("float32", "float16", "bfloat16") else np.float64

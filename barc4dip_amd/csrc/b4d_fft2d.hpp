@@ -552,9 +552,11 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
         if (!live) return;
         const bool norm = (p.flags & B4D_NORM_PEAK) != 0;
         float s = p.scale;
+        bool unit_peak = false;   // corr / max|corr| only if the peak is > 0 (signal/corr.py:247-250): a constant frame stays 0
         if (norm) {
             const float pk = p.peak[frame];
-            s = pk != 0.f ? 1.0f / pk : 1.0f;
+            unit_peak = pk > 0.f;
+            s = unit_peak ? 1.0f / pk : p.scale;
         }
         // half mode: rows 0..ny/2 are written directly, rows 1..ny/2-1 also as their point mirrors
         const bool wr1 = !p.half || y0 + 1 <= ny / 2;
@@ -566,7 +568,7 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
             const int x = u + T * j, c = (x + NX / 2) & (NX - 1), cm = (NX / 2 - x) & (NX - 1);
             float r0 = v[j].y * s;
             const float r1 = v[j].x * s;
-            if (norm && pair == 0 && x == 0) r0 = 1.0f;  // peak normalisation: zero lag is 1 by definition
+            if (unit_peak && pair == 0 && x == 0) r0 = 1.0f;  // peak normalisation: zero lag is 1 by definition
             o0[c] = r0;
             if (wr1) o1[c] = r1;
             if (mir0) q0[cm] = r0;

@@ -182,13 +182,14 @@ __global__ void __launch_bounds__(256) k_gen_real_out(const float2* __restrict__
     const size_t fo = (size_t)blockIdx.y * ny * nx;
     const int y = e / nx, x = e % nx;
     float s = scale;
-    const bool norm = (flags & B4D_NORM_PEAK) != 0;
-    if (norm) {
+    bool unit_peak = false;   // only a positive peak is normalised (signal/corr.py:247-250)
+    if ((flags & B4D_NORM_PEAK) != 0) {
         const float pk = R[fo].x;
-        s = pk != 0.f ? 1.0f / pk : 1.0f;
+        unit_peak = pk > 0.f;
+        if (unit_peak) s = 1.0f / pk;
     }
     float v = R[fo + e].x * s;
-    if (norm && e == 0) v = 1.0f;
+    if (unit_peak && e == 0) v = 1.0f;
     out[fo + (size_t)((y + ny / 2) % ny) * nx + (x + nx / 2) % nx] = v;
 }
 

@@ -104,7 +104,7 @@ def fft2d(image, *, x=None, y=None, dx: float = 1.0, dy: float = 1.0, return_ten
     ny, nx = image.shape
     fx, fy = freq_axes2d(shape=(ny, nx), x=x, y=y, dx=dx, dy=dy)
     F = fft2d_stack(image[None], return_tensors=True)[0]
-    src = np.float64 if (getattr(image, "dtype", None) in (np.float64,) or str(getattr(image, "dtype", "")) == "torch.float64") else np.float32
+    src = D.result_dtype(image)
     return _finish(F, True, return_tensors, np.complex128 if src is np.float64 else np.complex64), fx, fy
 
 
@@ -141,5 +141,4 @@ def psd2d(image, *, x=None, y=None, dx: float = 1.0, dy: float = 1.0, scale: boo
     sx, sy = _resolve_steps_2d(shape=(ny, nx), x=x, y=y, dx=dx, dy=dy)
     fx, fy = freq_axes2d(shape=(ny, nx), x=x, y=y, dx=dx, dy=dy)
     P = psd2d_stack(image[None], dx=sx, dy=sy, scale=scale, return_tensors=True)[0]
-    src = np.float64 if str(getattr(image, "dtype", "")) in ("float64", "torch.float64") else np.float32
-    return _finish(P, True, return_tensors, src), fx, fy
+    return _finish(P, True, return_tensors, D.result_dtype(image)), fx, fy

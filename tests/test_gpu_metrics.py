@@ -223,3 +223,60 @@ def test_stack_stats_default_tracker_any_size(gm):
             np.testing.assert_allclose(got["temporal"][blk][k], ref["temporal"][blk][k], atol=5e-3)
     np.testing.assert_allclose(got["temporal"]["abs"]["dy"], sh[:, 0], atol=0.25)
     np.testing.assert_allclose(got["temporal"]["abs"]["dx"], sh[:, 1], atol=0.25)
+
+
+@pytest.mark.parametrize("case", ["u16_384", "f64_300x420", "noncontig", "fortran", "int32_130", "withnan_512", "const_256", "zeros_256"])
+def test_awkward_inputs_match_oracle(gm, case):
+    """dtypes, strides, odd sizes, NaNs, constant frames: same values, same exception types and same result dtypes as the
+    oracle (NumPy promotes everything but float16/float32 to double precision; a constant frame's autocorrelation is 0)."""
+    from barc4dip_amd import signal as gs
+    from oracle import metrics_np as M
+    from oracle import signal_np as S
+
+    base = synth.speckle_frame(600, 3)
+    rng = np.random.default_rng(0)
+    img = {
+        "u16_384": lambda: base[:384, :384].astype(np.uint16),
+        "f64_300x420": lambda: base[:300, :420].astype(np.float64),
+        "noncontig": lambda: base[::2, ::2][:290, :290],
+        "fortran": lambda: np.asfortranarray(base[:256, :256]),
+        "int32_130": lambda: base[:130, :130].astype(np.int32),
+        "withnan_512": lambda: np.where(rng.random((512, 512)) < 1e-4, np.nan, base[:512, :512]).astype(np.float32),
+        "const_256": lambda: np.full((256, 256), 7.0, np.float32),
+        "zeros_256": lambda: np.zeros((256, 256), np.float32),
+    }[case]()
+
+    def both(f, g):
+        out = []
+        for fn in (f, g):
+            try:
+                out.append((fn(), None))
+            except Exception as e:  # noqa: BLE001
+                out.append((None, type(e).__name__))
+        assert out[0][1] == out[1][1], (case, out[0][1], out[1][1])
+        return out[0][0], out[1][0]
+
+    def walk(a, b, path):
+        for k, v in b.items():
+            if isinstance(v, dict):
+                walk(a[k], v, path + "/" + k)
+            elif isinstance(v, (float, int, np.floating)):
+                assert np.isclose(float(a[k]), float(v), rtol=2e-5, atol=1e-9, equal_nan=True), (case, path, k, a[k], v)
+            elif isinstance(v, np.ndarray) and v.dtype.kind == "f" and k != "autocorr":
+                np.testing.assert_allclose(np.asarray(a[k], float), v, rtol=2e-5, atol=1e-9, equal_nan=True, err_msg=f"{case}{path}/{k}")
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a, b = both(lambda: gm.speckle_stats(img, verbose=False), lambda: M.speckle_stats(img))
+        if a is not None:
+            walk(a, b, "speckle")
+        a, b = both(lambda: gm.sharpness_stats(img, verbose=False), lambda: M.sharpness_stats(img))
+        if a is not None:
+            walk(a, b, "sharpness")
+    for fn in ("fft2d", "psd2d", "autocorr2d"):
+        a, b = both(lambda: getattr(gs, fn)(img), lambda: getattr(S, fn)(img))
+        if a is not None:
+            x, y = np.asarray(a[0]), np.asarray(b[0])
+            assert x.dtype == y.dtype, (case, fn, x.dtype, y.dtype)
+            if np.isfinite(y).all():
+                assert np.max(np.abs(x - y)) <= 2e-5 * max(float(np.max(np.abs(y))), 1e-30), (case, fn)
