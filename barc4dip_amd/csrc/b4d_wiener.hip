@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, f
             for (int x = threadIdx.x; x < io.w; x += FT) {
                 const float2 z = buf0[x + io.px];
                 float v = (e == 0 ? z.x : -z.y) * scale;   // conj(buf0): real part row a, imaginary part row b
-                if (io.clip) v = fminf(fmaxf(v, -1.f), 1.f);
+                if (io.clip) v = (v > 1.f ? 1.f : (v < -1.f ? -1.f : v))   /* np.clip: NaN stays NaN */;
                 io.crop[(size_t)y * io.w + x] = fok ? v * fsc : 0.f;
             }
         }
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, f
         if (y < 0 || y >= io.h) return;
         for (int x = threadIdx.x; x < io.w; x += FT) {
             float v = buf0[x + io.px].x * scale;   // conj_io only flips the imaginary part
-            if (io.clip) v = fminf(fmaxf(v, -1.f), 1.f);
+            if (io.clip) v = (v > 1.f ? 1.f : (v < -1.f ? -1.f : v))   /* np.clip: NaN stays NaN */;
             io.crop[(size_t)y * io.w + x] = fok ? v * fsc : 0.f;
         }
         return;
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256) k_crop_out(const float2* __restrict__ z, 
     if (e >= (size_t)h * w) return;
     const int y = (int)(e / w), x = (int)(e % w), W = w + 2 * px;
     float v = z[(size_t)(y + py) * W + x + px].x;
-    if (clip) v = fminf(fmaxf(v, -1.f), 1.f);
+    if (clip) v = (v > 1.f ? 1.f : (v < -1.f ? -1.f : v))   /* np.clip: NaN stays NaN */;
     const float sc = s_scale;
     out[e] = (isfinite(sc) && sc != 0.f) ? v * sc : 0.f;
 }
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) k_rl_crop(const float* __restrict__ est, 
     if (e >= (size_t)h * w) return;
     const int y = (int)(e / w), x = (int)(e % w), W = w + 2 * px;
     float v = est[(size_t)(y + py) * W + x + px];
-    if (clip) v = fminf(fmaxf(v, -1.f), 1.f);
+    if (clip) v = (v > 1.f ? 1.f : (v < -1.f ? -1.f : v))   /* np.clip: NaN stays NaN */;
     const float sc = amax[0];
     out[e] = (isfinite(sc) && sc != 0.f) ? v * sc : 0.f;
 }

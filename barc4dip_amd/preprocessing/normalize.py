@@ -103,17 +103,20 @@ def flat_field_correction(images, *, flats=None, darks=None, scale: str = "flat_
         return done(out)
     dptr = D.ptr(dark2d) if dark2d is not None else null
     den = torch.empty((h, w), dtype=torch.float32, device=img.device)
+    _ffi.check(lib.b4d_flat_den(D.ptr(flat2d), dptr, npix, 0.0, 0, D.ptr(den), st))
+    med, n_ok = _median_f32(den)
+    den_has_nan = n_ok < npix            # a NaN denominator makes np.median / np.mean of it NaN (and it is never "bad")
     if eps is None:         # relative threshold from the median denominator (normalize.py:109-111)
-        _ffi.check(lib.b4d_flat_den(D.ptr(flat2d), dptr, npix, 0.0, 0, D.ptr(den), st))
-        med, n_ok = _median_f32(den)
-        if n_ok < npix:     # a NaN denominator makes np.median NaN
+        if den_has_nan:
             med = np.float32(np.nan)
         eps_f = np.float32(1e-6 * med) if med > 0 else np.float32(1e-6)
     else:
         eps_f = np.float32(eps)
     _ffi.check(lib.b4d_flat_den(D.ptr(flat2d), dptr, npix, float(eps_f), 1, D.ptr(den), st))   # NaN where den <= eps
     s = np.float32(1.0)
-    if scale == "flat_median":
+    if scale != "none" and den_has_nan:
+        s = np.float32(np.nan)
+    elif scale == "flat_median":
         s, _ = _median_f32(den)
     elif scale == "flat_mean":
         s = _mean_valid(den)

@@ -65,3 +65,28 @@ def test_flat_field_errors(prep):
         prep.flat_field_correction(im[0, 0], flats=G["flats"])
     with pytest.raises(ValueError):
         prep.flat_field_correction(im, flats=G["flats"][None])
+
+
+def test_nan_semantics(prep):
+    """NaN propagation like NumPy's: a NaN flat pixel makes the median / mean scale NaN (whole output NaN), np.clip keeps
+    NaN in deconvolve_psf (a NaN pixel spreads over the whole frame through the FFT)."""
+    from barc4dip_amd import synth
+    from oracle import preprocess_np as P
+    from oracle import wiener_np as W
+
+    img = synth.speckle_frame(200, 5)[:150, :180]
+    rng = np.random.default_rng(1)
+    flats = rng.poisson(2000, size=(3, 150, 180)).astype(np.float32)
+    darks = rng.poisson(100, size=(150, 180)).astype(np.float32)
+    flats[:, 3, 4] = np.nan
+    for kw in (dict(), dict(bad_pixel_removal=True), dict(scale="none"), dict(scale="flat_mean")):
+        got = prep.flat_field_correction(img, flats=flats, darks=darks, **kw)
+        want = P.flat_field_correction(img, flats=flats, darks=darks, **kw)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), kw
+        assert np.array_equal(got, want, equal_nan=True) or kw.get("scale") == "flat_mean"
+    nanimg = img.copy()
+    nanimg[5, 7] = np.nan
+    got, want = prep.deconvolve_psf(nanimg, sigma=1.0), W.deconvolve_psf(nanimg, sigma=1.0)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).all()
+    z = np.zeros_like(img)
+    assert np.array_equal(prep.deconvolve_psf(z, sigma=1.0), W.deconvolve_psf(z, sigma=1.0))
