@@ -315,7 +315,11 @@ __global__ void __launch_bounds__(256) k_sobel_fin(const double* __restrict__ pa
 // caller finishes lo + (hi - lo) * t in float64 exactly like NumPy's _lerp.   grid (batch), block 1024.
 __global__ void __launch_bounds__(1024) k_percentiles(const float* __restrict__ frames, size_t npix, const double* __restrict__ q,
                                                       int nq, double* __restrict__ out) {
-    __shared__ unsigned hist[2048];
+#ifndef B4D_PCT_REP
+#define B4D_PCT_REP 4
+#endif
+    constexpr int REP = B4D_PCT_REP;   // replicated histograms: intensity data crowd a few exponent bins (b4d_select.hpp)
+    __shared__ unsigned hist[2048 * REP];
     __shared__ unsigned sh[4];
     __shared__ unsigned s_cnt[16];
     const float* x = frames + (size_t)blockIdx.x * npix;
@@ -340,7 +344,7 @@ __global__ void __launch_bounds__(1024) k_percentiles(const float* __restrict__ 
         if (lo > n - 1) lo = n - 1;
         const unsigned hi = lo + 1 < n ? lo + 1 : n - 1;
         unsigned nl, ne;
-        const unsigned ka = radix_select(x, n_all, lo, hist, sh, nl, ne);
+        const unsigned ka = radix_select<REP>(x, n_all, lo, hist, sh, nl, ne);
         unsigned kb = ka;
         if (hi != lo && nl + ne <= hi) kb = next_larger_key(x, n_all, ka, hist);
         if (threadIdx.x == 0) {
@@ -351,6 +355,174 @@ __global__ void __launch_bounds__(1024) k_percentiles(const float* __restrict__ 
         }
         __syncthreads();
     }
+}
+
+// ---- the same selection spread over many workgroups (large frames: one workgroup would stream the map ~9 times alone)
+// State per (frame, query): st[0] = prefix, st[1] = elements below the current bin, st[2] = target rank, st[3] = count
+// in the chosen bin, st[4] = n_valid, st[5] = smallest key above the selected one (next-larger pass).
+struct PctMulti {
+    const float* frames;
+    size_t npix;
+    unsigned* hist;    // (batch, nq, 2048), zero on entry of every pass
+    unsigned* state;   // (batch, nq, 8)
+    const double* q;
+    double* out;
+    int nq;
+};
+
+// pass: 0, 1, 2 (bits 31..21, 20..10, 9..0).  grid (NB, batch, pass == 0 ? 1 : nq), block 256
+template <int PASS>
+__global__ void __launch_bounds__(256) k_pctm_hist(PctMulti p) {
+    constexpr int REP = 4;
+    __shared__ unsigned hist[2048 * REP];
+    const int f = blockIdx.y, j = blockIdx.z;
+    const float* x = p.frames + (size_t)f * p.npix;
+    const unsigned n = (unsigned)p.npix;
+    constexpr int sft = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0), nb = PASS == 2 ? 1024 : 2048;
+    constexpr unsigned mask = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
+    const unsigned prefix = PASS == 0 ? 0u : p.state[((size_t)f * p.nq + j) * 8];
+    for (int i = threadIdx.x; i < 2048 * REP; i += 256) hist[i] = 0;
+    __syncthreads();
+    unsigned* my = hist + (threadIdx.x % REP) * 2048;
+    auto visit = [&](float v) {
+        if (v != v) return;
+        const unsigned key = f2key(v);
+        if ((key & mask) == prefix) atomicAdd(&my[(key >> sft) & (nb - 1)], 1u);
+    };
+    const unsigned n4 = ((reinterpret_cast<size_t>(x) & 15) == 0) ? n / 4 : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const float4 a = x4[i];
+        visit(a.x); visit(a.y); visit(a.z); visit(a.w);
+    }
+    if (blockIdx.x == 0)
+        for (unsigned i = 4 * n4 + threadIdx.x; i < n; i += 256) visit(x[i]);
+    __syncthreads();
+    unsigned* g = p.hist + ((size_t)f * p.nq + j) * 2048;
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+        unsigned t = 0;
+#pragma unroll
+        for (int r = 0; r < REP; ++r) t += hist[r * 2048 + i];
+        if (t) atomicAdd(&g[i], t);
+    }
+}
+
+// choose the bin of the target rank, update the state, clear the histogram for the next pass.  grid (batch, nq), block 64.
+// PASS 0 reads the shared pass-0 histogram of query 0 and derives n_valid and the rank from q.
+template <int PASS>
+__global__ void __launch_bounds__(64) k_pctm_pick(PctMulti p) {
+    const int f = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    unsigned* st = p.state + ((size_t)f * p.nq + j) * 8;
+    unsigned* g = p.hist + ((size_t)f * p.nq + (PASS == 0 ? 0 : j)) * 2048;
+    constexpr int sft = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+    const int per = 2048 / 64;
+    unsigned s = 0;
+    for (int i = 0; i < per; ++i) s += g[lane * per + i];
+    unsigned incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const unsigned total = __shfl(incl, 63, 64);
+    unsigned kk;
+    if (PASS == 0) {
+        const unsigned n = total;
+        unsigned lo = 0;
+        if (n > 0) {
+            const double pos = p.q[j] / 100.0 * (double)(n - 1);
+            lo = (unsigned)floor(pos);
+            if (lo > n - 1) lo = n - 1;
+        }
+        kk = lo;
+        if (lane == 0) {
+            st[0] = 0;
+            st[1] = 0;
+            st[2] = lo;
+            st[4] = n;
+            st[5] = 0xffffffffu;
+        }
+    } else {
+        kk = st[2] - st[1];
+    }
+    __syncthreads();
+    const unsigned excl = incl - s;
+    if (total > 0 && kk >= excl && kk < incl) {
+        unsigned run = excl;
+        for (int i = 0; i < per; ++i) {
+            const unsigned c = g[lane * per + i];
+            if (kk < run + c) {
+                st[0] |= (unsigned)(lane * per + i) << sft;
+                st[1] += run;
+                st[3] = c;
+                break;
+            }
+            run += c;
+        }
+    }
+    __syncthreads();
+    if (PASS != 0 || j == gridDim.y - 1 || true) {   // every query's own histogram slot is cleared for the next pass
+        unsigned* mine = p.hist + ((size_t)f * p.nq + j) * 2048;
+        if (PASS != 0 || j != 0)
+            for (int i = lane; i < 2048; i += 64) mine[i] = 0;
+    }
+}
+
+// pass-0 histogram lives in slot 0 and is read by every query's pick: clear it afterwards.  grid (batch), block 256
+__global__ void __launch_bounds__(256) k_pctm_clear0(PctMulti p) {
+    unsigned* g = p.hist + (size_t)blockIdx.x * p.nq * 2048;
+    for (int i = threadIdx.x; i < 2048; i += 256) g[i] = 0;
+}
+
+// smallest key above the selected one.  grid (NB, batch, nq), block 256
+__global__ void __launch_bounds__(256) k_pctm_next(PctMulti p) {
+    __shared__ unsigned sh[4];
+    const int f = blockIdx.y, j = blockIdx.z;
+    const float* x = p.frames + (size_t)f * p.npix;
+    const unsigned n = (unsigned)p.npix;
+    unsigned* st = p.state + ((size_t)f * p.nq + j) * 8;
+    const unsigned ka = st[0];
+    unsigned best = 0xffffffffu;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float v = x[i];
+        if (v != v) continue;
+        const unsigned key = f2key(v);
+        if (key > ka && key < best) best = key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = __shfl_down(best, o, 64);
+        best = t < best ? t : best;
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) best = sh[i] < best ? sh[i] : best;
+        if (best != 0xffffffffu) atomicMin(&st[5], best);
+    }
+}
+
+// out[f][j] = {lo value, hi value, fraction, n_valid}.  grid (batch), block 64 (lane = query)
+__global__ void __launch_bounds__(64) k_pctm_out(PctMulti p) {
+    const int f = blockIdx.x, j = threadIdx.x;
+    if (j >= p.nq) return;
+    const unsigned* st = p.state + ((size_t)f * p.nq + j) * 8;
+    double* o = p.out + ((size_t)f * p.nq + j) * 4;
+    const unsigned n = st[4];
+    if (n == 0) {
+        o[0] = o[1] = nan("");
+        o[2] = 0.0;
+        o[3] = 0.0;
+        return;
+    }
+    const double pos = p.q[j] / 100.0 * (double)(n - 1);
+    const unsigned lo = st[2], hi = lo + 1 < n ? lo + 1 : n - 1;
+    unsigned kb = st[0];
+    if (hi != lo && st[1] + st[3] <= hi && st[5] != 0xffffffffu) kb = st[5];
+    o[0] = (double)key2f(st[0]);
+    o[1] = (double)key2f(kb);
+    o[2] = pos - (double)lo;
+    o[3] = (double)n;
 }
 
 // ------------------------------------------------------------------------------------ radial profile
@@ -613,15 +785,39 @@ int b4d_percentiles(const float* frames, int batch, size_t npix, const double* q
     if (!frames || !q_host || !out) return fail(B4D_EINVAL, "null argument");
     if (batch < 1 || npix < 1 || nq < 1 || nq > 16) return fail(B4D_EINVAL, "batch, npix >= 1 and 1 <= nq <= 16 required");
     if (npix > 0xffffffffull) return fail(B4D_EINVAL, "frame too large");
-    void* ws = nullptr;
-    int rc = get_scratch(sizeof(double) * 16, &ws);
-    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const bool multi = npix >= ((size_t)1 << 17);
+    const size_t hist_words = multi ? (size_t)batch * nq * 2048 : 0, state_words = multi ? (size_t)batch * nq * 8 : 0;
+    void* ws = nullptr;
+    int rc = get_scratch(sizeof(double) * 16 + sizeof(unsigned) * (hist_words + state_words), &ws);
+    if (rc) return rc;
     B4D_HIP(hipMemcpyAsync(ws, q_host, sizeof(double) * nq, hipMemcpyHostToDevice, st));
     B4D_HIP(hipStreamSynchronize(st));
-    hipLaunchKernelGGL(k_percentiles, dim3(batch), dim3(1024), 0, st, frames, npix, static_cast<const double*>(ws), nq, out);
+    if (!multi) {
+        hipLaunchKernelGGL(k_percentiles, dim3(batch), dim3(1024), 0, st, frames, npix, static_cast<const double*>(ws), nq, out);
+    } else {  // large frames: every pass of the radix select runs on the whole chip
+        PctMulti pm{};
+        pm.frames = frames;
+        pm.npix = npix;
+        pm.q = static_cast<const double*>(ws);
+        pm.hist = reinterpret_cast<unsigned*>(static_cast<double*>(ws) + 16);
+        pm.state = pm.hist + hist_words;
+        pm.out = out;
+        pm.nq = nq;
+        const int nbw = (int)std::min<size_t>(256, (npix / 4 + 255) / 256);
+        B4D_HIP(hipMemsetAsync(pm.hist, 0, sizeof(unsigned) * (hist_words + state_words), st));
+        hipLaunchKernelGGL((k_pctm_hist<0>), dim3(nbw, batch, 1), dim3(256), 0, st, pm);
+        hipLaunchKernelGGL((k_pctm_pick<0>), dim3(batch, nq), dim3(64), 0, st, pm);
+        hipLaunchKernelGGL(k_pctm_clear0, dim3(batch), dim3(256), 0, st, pm);
+        hipLaunchKernelGGL((k_pctm_hist<1>), dim3(nbw, batch, nq), dim3(256), 0, st, pm);
+        hipLaunchKernelGGL((k_pctm_pick<1>), dim3(batch, nq), dim3(64), 0, st, pm);
+        hipLaunchKernelGGL((k_pctm_hist<2>), dim3(nbw, batch, nq), dim3(256), 0, st, pm);
+        hipLaunchKernelGGL((k_pctm_pick<2>), dim3(batch, nq), dim3(64), 0, st, pm);
+        hipLaunchKernelGGL(k_pctm_next, dim3(nbw, batch, nq), dim3(256), 0, st, pm);
+        hipLaunchKernelGGL(k_pctm_out, dim3(batch), dim3(64), 0, st, pm);
+    }
     B4D_HIP(hipGetLastError());
-    B4D_HIP(hipStreamSynchronize(st));  // the shared scratch holds q until the kernel has run
+    B4D_HIP(hipStreamSynchronize(st));  // the shared scratch holds q (and the selection state) until the kernels have run
     return B4D_OK;
 }
 
