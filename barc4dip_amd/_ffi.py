@@ -40,6 +40,8 @@ SIGNATURES = {
     "b4d_version": (C.c_char_p, []),
     "b4d_last_error": (C.c_char_p, []),
     "b4d_size_supported": (_i, [_i, _i]),
+    "b4d_plan_create_general": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "b4d_fft2d_c2c": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "b4d_plan_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "b4d_plan_destroy": (_i, [_vp]),
     "b4d_plan_workspace_bytes": (_sz, [_vp]),
@@ -121,11 +123,12 @@ def require_gpu():
 class Plan:
     """RAII wrapper of b4d_plan (twiddles + chunk workspace) for one (ny, nx)."""
 
-    def __init__(self, ny: int, nx: int, chunk: int = 8):
+    def __init__(self, ny: int, nx: int, chunk: int = 8, general: bool = False):
         require_gpu()
         self.ny, self.nx, self.chunk = int(ny), int(nx), int(chunk)
         h = _vp()
-        check(lib().b4d_plan_create(self.ny, self.nx, self.chunk, C.byref(h)))
+        create = lib().b4d_plan_create_general if general else lib().b4d_plan_create
+        check(create(self.ny, self.nx, self.chunk, C.byref(h)))
         self._h = h
 
     @property
@@ -169,16 +172,18 @@ def default_chunk(ny: int, nx: int) -> int:
     return max(1, min(chunk, cap, 128))
 
 
-def get_plan(ny: int, nx: int, chunk: int | None = None) -> Plan:
+def get_plan(ny: int, nx: int, chunk: int | None = None, general: bool = False) -> Plan:
     import torch
 
+    if general and chunk is None:
+        chunk = max(1, min(128, (256 << 20) // (24 * int(ny) * int(nx))))
     # plans own device workspace: one per (device, stream), so that work queued on different streams never shares it
     key = (int(ny), int(nx), int(chunk or default_chunk(ny, nx)), torch.cuda.current_device(),
-           int(torch.cuda.current_stream().cuda_stream))
+           int(torch.cuda.current_stream().cuda_stream), bool(general))
     with _plans_lock:
         pl = _plans.get(key)
         if pl is None:
-            pl = Plan(key[0], key[1], key[2])
+            pl = Plan(key[0], key[1], key[2], general=general)
             _plans[key] = pl
         return pl
 

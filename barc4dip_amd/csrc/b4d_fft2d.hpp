@@ -646,6 +646,7 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
                          unsigned flags, hipStream_t st);
 int general_fft2d(b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st);
 int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, hipStream_t st);
+int general_fft2d_c2c(b4d_plan* pl, const float2* in, int batch, int inverse, float2* out, hipStream_t st);
 int general_dft2(const b4d_plan* pl, const void* X, bool x_real, int batch, int conj, float2* tmp, float2* F, hipStream_t st);
 // b4d_wiener.hip: general-length 1-D engine (n = P * A * B, in-LDS mixed radix) and batched complex transpose
 namespace b4d {

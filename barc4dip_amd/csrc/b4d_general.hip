@@ -164,6 +164,22 @@ __global__ void __launch_bounds__(256) k_gen_shift_c(const float2* __restrict__ 
     out[fo + (size_t)((ky + ny / 2) % ny) * nx + (kx + nx / 2) % nx] = F[fo + e];
 }
 
+// natural[k] = shifted[(k + n/2) % n] (np.fft.ifftshift of an fftshift-ed array), optionally scaled
+__global__ void __launch_bounds__(256) k_gen_unshift_c(const float2* __restrict__ F, int ny, int nx, float scale, float2* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ny * nx) return;
+    const size_t fo = (size_t)blockIdx.y * ny * nx;
+    const int ky = e / nx, kx = e % nx;
+    const float2 v = F[fo + (size_t)((ky + ny / 2) % ny) * nx + (kx + nx / 2) % nx];
+    out[fo + e] = make_float2(v.x * scale, v.y * scale);
+}
+
+__global__ void __launch_bounds__(256) k_gen_scale_c(const float2* __restrict__ F, size_t n, float scale, float2* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    out[e] = make_float2(F[e].x * scale, F[e].y * scale);
+}
+
 __global__ void __launch_bounds__(256) k_gen_cross(const float2* __restrict__ Fa, const float2* __restrict__ Fb, int npix,
                                                    float2* __restrict__ C, unsigned flags) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -282,6 +298,29 @@ int general_fft2d(b4d_plan* pl, const float* frames, int batch, float2* out, hip
         int rc = dft2(pl, frames + (size_t)b0 * npix, true, nb, 0, pl->gbuf1, pl->gbuf2, st);
         if (rc) return rc;
         hipLaunchKernelGGL(k_gen_shift_c, dim3((npix + 255) / 256, nb), dim3(256), 0, st, pl->gbuf2, ny, nx, out + (size_t)b0 * npix);
+        B4D_HIP(hipGetLastError());
+    }
+    return B4D_OK;
+}
+
+// complex input: forward = fftshift(fft2(x)) (signal/fft.py:198-237 for complex frames); inverse = ifft2(ifftshift(F))
+// (signal/fft.py:240-258), natural order out, scaled by 1 / (nx ny)
+int general_fft2d_c2c(b4d_plan* pl, const float2* in, int batch, int inverse, float2* out, hipStream_t st) {
+    const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
+    for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
+        const int nb = std::min(pl->chunk, batch - b0);
+        const size_t off = (size_t)b0 * npix;
+        int rc;
+        if (!inverse) {
+            if ((rc = dft2(pl, in + off, false, nb, 0, pl->gbuf1, pl->gbuf2, st))) return rc;
+            hipLaunchKernelGGL(k_gen_shift_c, dim3((npix + 255) / 256, nb), dim3(256), 0, st, pl->gbuf2, ny, nx, out + off);
+        } else {
+            hipLaunchKernelGGL(k_gen_unshift_c, dim3((npix + 255) / 256, nb), dim3(256), 0, st, in + off, ny, nx, 1.0f, pl->gbuf3);
+            if ((rc = dft2(pl, pl->gbuf3, false, nb, 1, pl->gbuf1, pl->gbuf2, st))) return rc;
+            const size_t n = (size_t)nb * npix;
+            hipLaunchKernelGGL(k_gen_scale_c, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl->gbuf2, n, 1.0f / ((float)nx * (float)ny),
+                               out + off);
+        }
         B4D_HIP(hipGetLastError());
     }
     return B4D_OK;

@@ -20,7 +20,18 @@ int b4d_size_supported(int ny, int nx) {
     return (pow2_ok(ny) && pow2_ok(nx)) || (general_ok(ny) && general_ok(nx)) || large_ok(ny, nx);
 }
 
-int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out) {
+static int plan_create_impl(int ny, int nx, int chunk, bool force_general, b4d_plan** out);
+int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out) { return plan_create_impl(ny, nx, chunk, false, out); }
+// complex-to-complex transforms (b4d_fft2d_c2c) run on the general-length engines for every size, powers of two included
+int b4d_plan_create_general(int ny, int nx, int chunk, b4d_plan** out) {
+    if (out) *out = nullptr;
+    if (!((general_ok(ny) && general_ok(nx)) || large_ok(ny, nx)))
+        return fail(B4D_ESIZE, "general plans need ny, nx <= 512 or sides up to 8192 that split as 2^k * A * B; got " +
+                                   std::to_string(ny) + "x" + std::to_string(nx));
+    return plan_create_impl(ny, nx, chunk, true, out);
+}
+
+static int plan_create_impl(int ny, int nx, int chunk, bool force_general, b4d_plan** out) {
     if (!out) return fail(B4D_EINVAL, "out is null");
     *out = nullptr;
     if (!b4d_size_supported(ny, nx))
@@ -32,7 +43,7 @@ int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out) {
     p->ny = ny;
     p->nx = nx;
     p->chunk = chunk;
-    if (!(pow2_ok(ny) && pow2_ok(nx))) {  // general-length plan
+    if (force_general || !(pow2_ok(ny) && pow2_ok(nx))) {  // general-length plan
         p->general = true;
         p->large = !(general_ok(ny) && general_ok(nx));
         int rc = B4D_OK;
@@ -236,6 +247,15 @@ int b4d_fft2d(b4d_plan* pl, const float* frames, int batch, float* out_c64, void
         if (rc) return rc;
     }
     return B4D_OK;
+}
+
+int b4d_fft2d_c2c(b4d_plan* pl, const float* in_c64, int batch, int inverse, float* out_c64, void* stream) {
+    if (!pl || !in_c64 || !out_c64) return fail(B4D_EINVAL, "null argument");
+    if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
+    if (!pl->general) return fail(B4D_EINVAL, "b4d_fft2d_c2c needs a plan from b4d_plan_create_general");
+    B4D_PLAN_LOCK(pl);
+    return general_fft2d_c2c(pl, reinterpret_cast<const float2*>(in_c64), batch, inverse, reinterpret_cast<float2*>(out_c64),
+                             (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -93,29 +93,56 @@ def fft2d_stack(stack, *, return_tensors: bool = False):
     return _finish(out, True, return_tensors, np.complex128 if src is np.float64 else np.complex64)
 
 
+def _c2c(frames, inverse: bool):
+    """(B, ny, nx) complex frames through b4d_fft2d_c2c on a general-length plan -> complex64 device tensor."""
+    torch = _ffi.require_gpu()
+    t = frames if D.is_tensor(frames) else torch.from_numpy(np.ascontiguousarray(frames))
+    t = t.to(device="cuda", dtype=torch.complex64).contiguous()
+    b, ny, nx = (int(v) for v in t.shape)
+    pl = _ffi.get_plan(ny, nx, general=True)
+    out = torch.empty_like(t)
+    _ffi.check(_ffi.lib().b4d_fft2d_c2c(pl.handle, D.ptr(torch.view_as_real(t)), b, int(bool(inverse)), D.ptr(torch.view_as_real(out)),
+                                        _ffi.stream_ptr()))
+    return out
+
+
+def _is_complex(a) -> bool:
+    return bool(a.is_complex()) if D.is_tensor(a) else np.iscomplexobj(a)
+
+
+def _complex_result_dtype(a):
+    name = str(getattr(a, "dtype", "complex128")).replace("torch.", "")
+    return np.complex64 if name == "complex64" else np.complex128
+
+
 def fft2d(image, *, x=None, y=None, dx: float = 1.0, dy: float = 1.0, return_tensors: bool = False):
     """Shifted 2-D FFT of an image and shifted frequency axes (reference: signal/fft.py:198-237).
 
-    Returns (F (ny, nx) complex, fx (nx,), fy (ny,)).  Raises ValueError if image is not 2-D."""
+    Returns (F (ny, nx) complex, fx (nx,), fy (ny,)).  Raises ValueError if image is not 2-D.  Complex input runs the
+    complex-to-complex transform of the general-length engines (b4d_fft2d_c2c)."""
     if not D.is_tensor(image):
         image = np.asarray(image)
     if image.ndim != 2:
         raise ValueError("image must be a 2D array.")
     ny, nx = image.shape
     fx, fy = freq_axes2d(shape=(ny, nx), x=x, y=y, dx=dx, dy=dy)
+    if _is_complex(image):
+        F = _c2c(image[None], False)[0]
+        return _finish(F, True, return_tensors, _complex_result_dtype(image)), fx, fy
     F = fft2d_stack(image[None], return_tensors=True)[0]
     src = D.result_dtype(image)
     return _finish(F, True, return_tensors, np.complex128 if src is np.float64 else np.complex64), fx, fy
 
 
-def ifft2d(F):
-    """Inverse FFT from a shifted spectrum (reference: signal/fft.py:240-258).
-
-    Complex-input transform; kept on the host (not on the measured path)."""
-    F = np.asarray(F)
+def ifft2d(F, *, return_tensors: bool = False):
+    """Inverse FFT from a shifted spectrum, ifft2(ifftshift(F)) (reference: signal/fft.py:240-258), on the device
+    (b4d_fft2d_c2c, complex64 arithmetic; complex128 input is cast down and the result cast back up)."""
+    if not D.is_tensor(F):
+        F = np.asarray(F)
     if F.ndim != 2:
         raise ValueError("F must be a 2D array.")
-    return np.fft.ifft2(np.fft.ifftshift(F))
+    out = _c2c(F[None], True)[0]
+    return _finish(out, True, return_tensors, _complex_result_dtype(F) if _is_complex(F) else np.complex128)
 
 
 def psd2d_stack(stack, *, dx: float = 1.0, dy: float = 1.0, scale: bool = True, return_tensors: bool = False):

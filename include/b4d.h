@@ -57,6 +57,13 @@ size_t b4d_plan_workspace_bytes(const b4d_plan* plan);
  * out: (batch, ny, nx) complex64 interleaved (re, im).                                  */
 int b4d_fft2d(b4d_plan* plan, const float* frames, int batch, float* out_c64, void* stream);
 
+/* Complex frames (signal/fft.py:198-258 accept complex input): plans from b4d_plan_create_general run the
+ * general-length engines (DFT matrices up to 512, fused mixed radix beyond) for every size, powers of two included.
+ * inverse == 0: out = fftshift(fft2(in));  inverse != 0: out = ifft2(ifftshift(in)), i.e. ifft2d of a shifted spectrum.
+ * in / out: DEVICE (batch, ny, nx) complex64 (interleaved float pairs).                                               */
+int b4d_plan_create_general(int ny, int nx, int chunk, b4d_plan** out);
+int b4d_fft2d_c2c(b4d_plan* plan, const float* in_c64, int batch, int inverse, float* out_c64, void* stream);
+
 /* signal/fft.py:261-309 psd2d -- P = |fftshift(fft2(img))|^2 * scale, scale = dx*dy/(nx*ny)
  * when scale=True else 1.  psd: (batch, ny, nx) float32.                                */
 int b4d_psd2d(b4d_plan* plan, const float* frames, int batch, float* psd, float scale, void* stream);

@@ -116,7 +116,7 @@ def test_errors(gs):
     with pytest.raises(NotImplementedError):
         gs.autocorr2d(np.zeros((1042, 2048), dtype=np.float32))
     with pytest.raises(NotImplementedError):
-        gs.fft2d(np.zeros((512, 512), dtype=np.complex64))
+        gs.psd2d(np.zeros((512, 512), dtype=np.complex64))             # PSD / correlations take real frames only
 
 
 def test_stack_equals_frames_and_chunking(gs):
@@ -282,3 +282,21 @@ def test_thread_reentrancy(gs):
         threaded = list(ex.map(work, frames))
     for a, b in zip(serial, threaded):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (100, 37), (512, 512), (300, 520), (1024, 2048)])
+def test_complex_fft2d_and_ifft2d(gs, shape):
+    """Complex frames (signal/fft.py:198-258): fft2d through the complex-to-complex engine, ifft2d on the device,
+    round trip ifft2d(fft2d(x)) == x; complex64 in -> complex64 out, complex128 in -> complex128 out."""
+    from oracle import signal_np as S
+
+    rng = np.random.default_rng(shape[0] + shape[1])
+    z = (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(np.complex64)
+    F, fx, fy = gs.fft2d(z, dx=0.5)
+    Fr, fxr, fyr = S.fft2d(z.astype(np.complex128), dx=0.5)
+    assert F.dtype == np.complex64 and nerr(F, Fr) < TOL and np.array_equal(fx, fxr) and np.array_equal(fy, fyr)
+    back = gs.fft.ifft2d(F)
+    assert back.dtype == np.complex64 and nerr(back, z) < TOL
+    assert nerr(gs.fft.ifft2d(Fr), S.ifft2d(Fr)) < TOL and gs.fft.ifft2d(Fr).dtype == np.complex128
+    real = rng.random(shape).astype(np.float32)
+    assert nerr(gs.fft.ifft2d(gs.fft2d(real)[0]).real, real) < TOL
