@@ -21,7 +21,7 @@ from . import kernels as K
 from .common import (apply_display_origin, choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
                      tile_spans, tiled_scalar_fields, tiles_meta)
 from .speckles import (_dev2d, _fft_ok, _pad4, _pad_square_batch, _pad_square_dev, _tile_batches, _widths_batch, _widths_from_autocorr,
-                       tiled_fields_batched)
+                       tiled_fields_batched, tiled_fields_batched_multi)
 from .statistics import distribution_moments, moments_from_sums
 
 logger = logging.getLogger(__name__)
@@ -212,41 +212,112 @@ def eigenvalues(image, *, k: int = 5, eps: float = 1e-30, verbose: bool = False)
     return out
 
 
-def _tiles_pointwise(t, tile_mode, groups, saturation_value, eps):
-    n, batches = _tile_batches(t, tile_mode)
+def _tiles_pointwise_multi(tb, tile_mode, groups, saturation_value, eps) -> list[dict]:
+    """Per frame of a (B, H, W) device stack: stats / gradient / laplacian / eigenvalues tile grids, every kernel launched
+    once per tile shape over the tiles of all frames."""
+    b = int(tb.shape[0])
+    n, batches = _tile_batches(tb, tile_mode)
     st = grad = lap = eigs = None
-    for _, rcs, stack in batches:
+    for _, frcs, stack in batches:
         mom = K.moments_batch(_pad4(stack), eps=eps, saturation=saturation_value).cpu().numpy() if "stats" in groups else None
         sl = K.sobel_laplace_batch(stack).cpu().numpy() if groups & {"gradient", "laplacian"} else None
         ev = _eigenvalues_batch(stack) if "eigenvalues" in groups else None
-        for i, (r, c) in enumerate(rcs):
+        for i, (f, r, c) in enumerate(frcs):
             if ev is not None:
-                eigs = eigs or {k: np.empty((n, n)) for k in ev[i]}
+                eigs = eigs or {k: np.empty((b, n, n)) for k in ev[i]}
                 for k in eigs:
-                    eigs[k][r, c] = ev[i][k]
+                    eigs[k][f, r, c] = ev[i][k]
             if mom is not None:
                 d = moments_from_sums(mom[i], saturation_value)
-                st = st or {k: np.empty((n, n)) for k in d}
+                st = st or {k: np.empty((b, n, n)) for k in d}
                 for k in st:
-                    st[k][r, c] = d[k]
+                    st[k][f, r, c] = d[k]
             if "gradient" in groups:
                 g = _gradient_from(sl[i], 1e-12)
-                grad = grad or {k: np.empty((n, n)) for k in g}
+                grad = grad or {k: np.empty((b, n, n)) for k in g}
                 for k in grad:
-                    grad[k][r, c] = g[k]
+                    grad[k][f, r, c] = g[k]
             if "laplacian" in groups:
-                lap = lap if lap is not None else {"laplacian_variance": np.empty((n, n))}
-                lap["laplacian_variance"][r, c] = float(sl[i][3] - sl[i][2] * sl[i][2])
-    out = {}
-    if st is not None:
-        out["stats"] = grids_to_fields(st, n)
-    if grad is not None:
-        out["gradient"] = grids_to_fields(grad, n)
-    if lap is not None:
-        out["laplacian"] = grids_to_fields(lap, n)
-    if eigs is not None:
-        out["eigenvalues"] = grids_to_fields(eigs, n)
-    return out
+                lap = lap if lap is not None else {"laplacian_variance": np.empty((b, n, n))}
+                lap["laplacian_variance"][f, r, c] = float(sl[i][3] - sl[i][2] * sl[i][2])
+    outs = []
+    for f in range(b):
+        out = {}
+        for name, grids in (("stats", st), ("gradient", grad), ("laplacian", lap), ("eigenvalues", eigs)):
+            if grids is not None:
+                out[name] = grids_to_fields({k: g[f] for k, g in grids.items()}, n)
+        outs.append(out)
+    return outs
+
+
+def _tiles_pointwise(t, tile_mode, groups, saturation_value, eps):
+    return _tiles_pointwise_multi(t[None], tile_mode, groups, saturation_value, eps)[0]
+
+
+def sharpness_stats_batch(tb, *, groups: set, tiles: bool = True, saturation_value: float | None = 65535.0,
+                          eps: float = 1e-6) -> list[dict]:
+    """{"full": ..., "tiles": ...} of every frame of a (B, H, W) device stack (already in display orientation): the
+    arithmetic of sharpness_stats, kernels launched once per batch / tile shape (used by sharpness_stack_stats)."""
+    import torch
+
+    b, h, w = (int(v) for v in tb.shape)
+    if h * w == 0:
+        raise ValueError("sharpness_stats received an empty image.")
+    outs = [{"full": {}} for _ in range(b)]
+    fin = tb.isfinite()
+    any_fin = fin.reshape(b, -1).any(dim=1)
+    all_fin = bool(fin.all())
+    if groups & {"stats", "gradient", "laplacian"} and not bool(any_fin.all()):
+        raise ValueError("sharpness_stats received image with no finite values.")
+    if "stats" in groups:
+        mom = K.moments_batch(_pad4(tb), eps=eps, saturation=saturation_value).cpu().numpy()
+        for f in range(b):
+            outs[f]["full"]["stats"] = moments_from_sums(mom[f], saturation_value)
+    if groups & {"gradient", "laplacian"}:
+        sl = K.sobel_laplace_batch(tb).cpu().numpy()
+        for f in range(b):
+            if "gradient" in groups:
+                outs[f]["full"]["gradient"] = _gradient_from(sl[f], 1e-12)
+            if "laplacian" in groups:
+                outs[f]["full"]["laplacian"] = {"laplacian_variance": float(sl[f][3] - sl[f][2] * sl[f][2])}
+    if groups & {"spectral", "eigenvalues"} and not all_fin:
+        raise ValueError("spectral_entropy / eigenvalues require all values to be finite.")
+    if "spectral" in groups:
+        for f, d in enumerate(_spectral_entropy_batch(tb)):
+            outs[f]["full"]["spectral"] = d
+    if "autocorrelation" in groups:
+        for f, d in enumerate(_inverse_autocorr_width_batch(tb)):
+            outs[f]["full"]["autocorrelation"] = d
+    if "eigenvalues" in groups:
+        energy = torch.sqrt((tb.double() ** 2).sum(dim=(1, 2)))
+        if not bool((torch.isfinite(energy) & (energy > 0)).all()):
+            raise ValueError("eigenvalues cannot normalize an all-zero image.")
+        if h * w - 1 <= 0:
+            raise ValueError("eigenvalues requires at least 2 pixels (M*N >= 2).")
+        for f, d in enumerate(_eigenvalues_batch(tb.contiguous())):
+            outs[f]["full"]["eigenvalues"] = d
+    mode, tile_shape_px = choose_tiling_mode(h, w, tiles=tiles, min_tile_px=128)
+    if mode == "off":
+        return outs
+    tiles_out = _tiles_pointwise_multi(tb, mode, groups, saturation_value, eps)
+    fft_groups = sorted(groups & _FFT_GROUPS)
+    if fft_groups:
+        n, ys, xs = tile_spans(h, w, mode)
+        if all(_fft_ok((y1 - y0, x1 - x0)) for y0, y1 in ys for x0, x1 in xs):
+            if "spectral" in groups:
+                for f, d in enumerate(tiled_fields_batched_multi(tb, mode, _spectral_entropy_batch)):
+                    tiles_out[f]["spectral"] = d
+            if "autocorrelation" in groups:
+                for f, d in enumerate(tiled_fields_batched_multi(tb, mode, _inverse_autocorr_width_batch)):
+                    tiles_out[f]["autocorrelation"] = d
+        else:
+            warnings.warn(f"tile statistics of {fft_groups} skipped: {tile_shape_px}-pixel tiles have no transform plan; "
+                          "full-frame values are unaffected.", RuntimeWarning, stacklevel=2)
+    order = ("stats", "gradient", "laplacian", "spectral", "autocorrelation", "eigenvalues")
+    for f in range(b):
+        if tiles_out[f]:
+            outs[f]["tiles"] = {g: tiles_out[f][g] for g in order if g in tiles_out[f]}
+    return outs
 
 
 def sharpness_stats(image: np.ndarray, *, metrics: str | Sequence[str] = "all", tiles: bool = True,
@@ -313,8 +384,17 @@ def sharpness_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "
         raise ValueError("stack must contain at least one frame.")
     groups = normalize_groups(metrics, all_groups=_ALL_SHARPNESS_GROUPS, context="sharpness", param_name="metrics")
     tile_mode, tile_shape_px = choose_tiling_mode(H, W, tiles=tiles)
-    per_frame = [sharpness_stats(stack[t], metrics=metrics, tiles=tiles, display_origin=display_origin,
-                                 saturation_value=saturation_value, eps=eps, verbose=False) for t in range(T)]
+    from .common import normalize_display_origin
+
+    lower = normalize_display_origin(display_origin) == "lower"
+    dev_all, _, _ = D.to_device_f32(stack, ndim=(3,))
+    fb = max(1, min(T, (256 << 20) // (4 * H * W)))     # frames per batch: <= 256 MiB of pixels
+    per_frame = []
+    for a in range(0, T, fb):
+        tb = dev_all[a:a + fb]
+        if lower:                                       # apply_display_origin: rows flipped before the metrics
+            tb = tb.flip(1).contiguous()
+        per_frame.extend(sharpness_stats_batch(tb, groups=groups, tiles=tiles, saturation_value=saturation_value, eps=eps))
     meta = {"kind": "sharpness_stack_stats", "input_shape": (H, W), "stack_shape": (T, H, W), "n_frames": T,
             "display_origin": display_origin, "requested_groups": sorted(groups), "units": _SHARPNESS_UNITS,
             "parallel": {"enabled": False, "n_jobs": None}}

@@ -173,19 +173,25 @@ def _bandwidth_batch(stack) -> list[dict]:
     return [_bandwidth_from(row) for row in K.psd_stats_batch(psd)]
 
 
-def tiled_fields_batched(t, tile_mode: str, batch_fn) -> dict:
-    """{key: {"mean": (3, 3), "std": (3, 3)}} from batch_fn((B, th, tw) stack) -> [dict] evaluated once per tile shape
-    (the batched form of metrics/common.py:278-378)."""
-    n, batches = _tile_batches(t, tile_mode)
+def tiled_fields_batched_multi(tb, tile_mode: str, batch_fn) -> list[dict]:
+    """Per frame of a (B, H, W) device stack: {key: {"mean": (3, 3), "std": (3, 3)}} from batch_fn((k, th, tw) stack) ->
+    [dict], evaluated once per tile shape over the tiles of ALL frames (the batched form of metrics/common.py:278-378)."""
+    b = int(tb.shape[0])
+    n, batches = _tile_batches(tb, tile_mode)
     grids = None
-    for _, rcs, stack in batches:
+    for _, frcs, stack in batches:
         vals = batch_fn(stack)
         if grids is None:
-            grids = {k: np.empty((n, n), dtype=float) for k in vals[0]}
-        for (r, c), v in zip(rcs, vals):
+            grids = {k: np.empty((b, n, n), dtype=float) for k in vals[0]}
+        for (f, r, c), v in zip(frcs, vals):
             for k in grids:
-                grids[k][r, c] = float(v[k])
-    return grids_to_fields(grids, n)
+                grids[k][f, r, c] = float(v[k])
+    return [grids_to_fields({k: g[f] for k, g in grids.items()}, n) for f in range(b)]
+
+
+def tiled_fields_batched(t, tile_mode: str, batch_fn) -> dict:
+    """Single-frame form of tiled_fields_batched_multi."""
+    return tiled_fields_batched_multi(t[None], tile_mode, batch_fn)[0]
 
 
 # ------------------------------------------------------------------------------------------------ metric functions
@@ -255,46 +261,112 @@ def bandwidth(image, verbose: bool = False) -> dict[str, float]:
 
 
 # ------------------------------------------------------------------------------------------------ tiles
-def _tile_batches(t, tile_mode: str):
-    """Tiles of a device image grouped by shape -> (n, [(shape, rc_list, stacked (k, th, tw) tensor)])."""
+def _tile_batches(tb, tile_mode: str):
+    """Tiles of a (B, H, W) device stack grouped by shape -> (n, [(shape, [(frame, r, c), ...], (k, th, tw) tensor)]);
+    within a group the tiles are ordered tile-major, frame-minor."""
     import torch
 
-    n, ys, xs = tile_spans(int(t.shape[0]), int(t.shape[1]), tile_mode)
+    b = int(tb.shape[0])
+    n, ys, xs = tile_spans(int(tb.shape[1]), int(tb.shape[2]), tile_mode)
     groups: dict[tuple[int, int], list] = {}
     for r, (y0, y1) in enumerate(ys):
         for c, (x0, x1) in enumerate(xs):
-            groups.setdefault((y1 - y0, x1 - x0), []).append((r, c, t[y0:y1, x0:x1]))
+            groups.setdefault((y1 - y0, x1 - x0), []).append((r, c, tb[:, y0:y1, x0:x1]))
     out = []
     for shape, items in groups.items():
-        out.append((shape, [(r, c) for r, c, _ in items], torch.stack([v for _, _, v in items]).contiguous()))
+        frcs = [(f, r, c) for r, c, _ in items for f in range(b)]
+        out.append((shape, frcs, torch.cat([v for _, _, v in items], dim=0).contiguous()))
     return n, out
 
 
-def _tiles_pointwise(t, tile_mode: str, want_amp: bool, want_stats: bool, saturation_value, eps):
-    """amplitude / stats tile grids from batched kernels over all tiles."""
-    n, batches = _tile_batches(t, tile_mode)
-    amp = {k: np.empty((n, n)) for k in ("visibility", "contrast")} if want_amp else None
+def _tiles_pointwise_multi(tb, tile_mode: str, want_amp: bool, want_stats: bool, saturation_value, eps) -> list[dict]:
+    """Per frame: amplitude / stats tile grids from batched kernels over the tiles of all frames."""
+    b = int(tb.shape[0])
+    n, batches = _tile_batches(tb, tile_mode)
+    amp = {k: np.empty((b, n, n)) for k in ("visibility", "contrast")} if want_amp else None
     st = None
-    for _, rcs, stack in batches:
+    for _, frcs, stack in batches:
         mom = K.moments_batch(_pad4(stack), eps=eps, saturation=saturation_value).cpu().numpy()
         pct = K.percentiles_batch(stack, [0.05, 99.95]) if want_amp else None
-        for i, (r, c) in enumerate(rcs):
+        for i, (f, r, c) in enumerate(frcs):
             if want_amp:
                 a = _amplitude_from(mom[i], pct[i])
                 for k in amp:
-                    amp[k][r, c] = a[k]
+                    amp[k][f, r, c] = a[k]
             if want_stats:
                 d = moments_from_sums(mom[i], saturation_value)
                 if st is None:
-                    st = {k: np.empty((n, n)) for k in d}
+                    st = {k: np.empty((b, n, n)) for k in d}
                 for k in st:
-                    st[k][r, c] = d[k]
-    out = {}
-    if want_amp:
-        out["amplitude"] = grids_to_fields(amp, n)
-    if want_stats:
-        out["stats"] = grids_to_fields(st, n)
-    return out
+                    st[k][f, r, c] = d[k]
+    outs = []
+    for f in range(b):
+        out = {}
+        if want_amp:
+            out["amplitude"] = grids_to_fields({k: g[f] for k, g in amp.items()}, n)
+        if want_stats:
+            out["stats"] = grids_to_fields({k: g[f] for k, g in st.items()}, n)
+        outs.append(out)
+    return outs
+
+
+def _tiles_pointwise(t, tile_mode: str, want_amp: bool, want_stats: bool, saturation_value, eps):
+    return _tiles_pointwise_multi(t[None], tile_mode, want_amp, want_stats, saturation_value, eps)[0]
+
+
+def speckle_stats_batch(tb, *, groups: set, tiles: bool = True, saturation_value: float | None = 65535.0, eps: float = 1e-6,
+                        keep_autocorr: bool = True) -> list[dict]:
+    """{"full": ..., "tiles": ...} of every frame of a (B, H, W) device stack (already in display orientation): the
+    arithmetic of speckle_stats with every kernel launched once per batch and tile shape instead of once per frame and
+    tile.  Used by speckle_stack_stats; equal to the per-frame function (tests/test_gpu_metrics.py)."""
+    b, h, w = (int(v) for v in tb.shape)
+    outs = [{"full": {}} for _ in range(b)]
+    if groups & {"amplitude", "stats"}:
+        mom = K.moments_batch(_pad4(tb), eps=eps, saturation=saturation_value).cpu().numpy()
+        pct = K.percentiles_batch(tb, [0.05, 99.95]) if "amplitude" in groups else None
+        for f in range(b):
+            if "amplitude" in groups:
+                outs[f]["full"]["amplitude"] = _amplitude_from(mom[f], pct[f])
+    if "grain" in groups:
+        if min(h, w) < 128:
+            raise ValueError("image too small for speckle grain metrics (min dimension < 128).")
+        sq = _pad_square_batch(tb)
+        ac = _corr.autocorr2d_stack(sq, remove_mean=True, standardize=False, normalize="peak", return_tensors=True)
+        n_sq = int(sq.shape[1])
+        xlag = (np.arange(n_sq) - n_sq // 2).astype(float)
+        ac_host = D.to_host(ac, np.float64) if keep_autocorr else None
+        for f, (lx, ly, leq) in enumerate(_widths_batch(ac, 1.0 / np.e)):
+            g = {"lx": lx, "ly": ly, "leq": float(leq), "r": float(lx / ly) if ly != 0 else float("inf")}
+            if keep_autocorr:
+                g.update({"autocorr": ac_host[f], "xlag": xlag, "ylag": xlag.copy()})
+            outs[f]["full"]["grain"] = g
+    if "stats" in groups:
+        for f in range(b):
+            outs[f]["full"]["stats"] = moments_from_sums(mom[f], saturation_value)
+    if "bandwidth" in groups:
+        for f, d in enumerate(_bandwidth_batch(tb)):
+            outs[f]["full"]["bandwidth"] = d
+    mode, tile_shape_px = choose_tiling_mode(h, w, tiles=tiles, min_tile_px=128)
+    if mode == "off":
+        return outs
+    tiles_out = _tiles_pointwise_multi(tb, mode, "amplitude" in groups, "stats" in groups, saturation_value, eps)
+    fft_groups = sorted(groups & _FFT_GROUPS)
+    if fft_groups:
+        n, ys, xs = tile_spans(h, w, mode)
+        if all(_fft_ok((y1 - y0, x1 - x0)) for y0, y1 in ys for x0, x1 in xs):
+            if "grain" in groups:
+                for f, d in enumerate(tiled_fields_batched_multi(tb, mode, _grain_batch)):
+                    tiles_out[f]["grain"] = d
+            if "bandwidth" in groups:
+                for f, d in enumerate(tiled_fields_batched_multi(tb, mode, _bandwidth_batch)):
+                    tiles_out[f]["bandwidth"] = d
+        else:
+            warnings.warn(f"tile statistics of {fft_groups} skipped: {tile_shape_px}-pixel tiles have no transform plan; "
+                          "full-frame values are unaffected.", RuntimeWarning, stacklevel=2)
+    for f in range(b):
+        if tiles_out[f]:
+            outs[f]["tiles"] = {g: tiles_out[f][g] for g in ("amplitude", "grain", "stats", "bandwidth") if g in tiles_out[f]}
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------ aggregators
@@ -375,8 +447,18 @@ def speckle_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "al
     else:
         raise ValueError(f"Unsupported tracking method: {tracking_method!r}. Supported: phase, template")
 
-    per_frame = [speckle_stats(stack[t], metrics=metrics, tiles=tiles, display_origin=display_origin,
-                               saturation_value=saturation_value, eps=eps, verbose=False) for t in range(T)]
+    groups = normalize_groups(metrics, all_groups=_ALL_SPECKLE_GROUPS, context="speckles", param_name="metrics")
+    from .common import normalize_display_origin
+
+    lower = normalize_display_origin(display_origin) == "lower"
+    dev_all, _, _ = D.to_device_f32(stack, ndim=(3,))
+    fb = max(1, min(T, (256 << 20) // (4 * H * W)))     # frames per batch: <= 256 MiB of pixels
+    per_frame = []
+    for a in range(0, T, fb):
+        tb = dev_all[a:a + fb]
+        if lower:                                       # apply_display_origin (common.py:44-72): rows flipped before the metrics
+            tb = tb.flip(1).contiguous()
+        per_frame.extend(speckle_stats_batch(tb, groups=groups, tiles=tiles, saturation_value=saturation_value, eps=eps))
     out_full = stack_time_series([d["full"] for d in per_frame])
     out_tiles = None
     if tiles and all(isinstance(d.get("tiles"), dict) for d in per_frame):
@@ -396,7 +478,7 @@ def speckle_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "al
     tpl_roi = rois + rois * T
     pair_img = [t for t in range(T) for _ in range(9)] * 2
     pair_tpl = [k for _ in range(T) for k in range(9)] + [9 + 9 * t + k for t in range(T) for k in range(9)]
-    dev, _, _ = D.to_device_f32(stack, ndim=(3,))
+    dev = dev_all
     if method == "template":
         res = template_matching_batch(dev, dev, tpl_frame, tpl_roi, pair_img, pair_tpl, backend=tracking_backend,
                                       subpixel=subpixel, eps=1e-9)

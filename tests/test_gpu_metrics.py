@@ -280,3 +280,35 @@ def test_awkward_inputs_match_oracle(gm, case):
             assert x.dtype == y.dtype, (case, fn, x.dtype, y.dtype)
             if np.isfinite(y).all():
                 assert np.max(np.abs(x - y)) <= 2e-5 * max(float(np.max(np.abs(y))), 1e-30), (case, fn)
+
+
+def test_batched_stack_path_equals_per_frame(gm):
+    """speckle_stack_stats / sharpness_stack_stats batch the kernels over frames and tile shapes; every per-frame value
+    must equal the single-frame aggregator's (same kernels, same operands: bit-identical scalars; STA2 eigenvalues to
+    1e-6, their subspace iteration stops on a per-batch criterion)."""
+    stack = np.stack([synth.speckle_frame(512, 60 + i) for i in range(3)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for origin in ("lower", "upper"):
+            res = gm.speckle_stack_stats(stack, display_origin=origin, roi_grain_factor=20.0, tracking_method="phase",
+                                         tracking_backend="internal", verbose=False)
+            sh = gm.sharpness_stack_stats(stack, display_origin=origin, verbose=False)
+            for t in range(3):
+                one = gm.speckle_stats(stack[t], display_origin=origin, verbose=False)
+                one_s = gm.sharpness_stats(stack[t], display_origin=origin, verbose=False)
+
+                def walk(a, b, path):
+                    for k, v in b.items():
+                        if isinstance(v, dict):
+                            walk(a[k], v, path + "/" + k)
+                        else:
+                            got = np.asarray(a[k])[t]
+                            if "eigenvalues" in path:   # iterative solver: the stop cycle depends on the batch it runs in
+                                np.testing.assert_allclose(np.asarray(got, float), np.asarray(v, float), rtol=1e-6, err_msg=f"{path}/{k}")
+                            else:
+                                assert np.array_equal(np.asarray(got, float), np.asarray(v, float), equal_nan=True), (origin, t, path, k)
+
+                walk(res["full"], one["full"], "speckle/full")
+                walk(res["tiles"], one["tiles"], "speckle/tiles")
+                walk(sh["full"], one_s["full"], "sharp/full")
+                walk(sh["tiles"], one_s["tiles"], "sharp/tiles")
