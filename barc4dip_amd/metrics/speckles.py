@@ -315,7 +315,7 @@ def _tiles_pointwise(t, tile_mode: str, want_amp: bool, want_stats: bool, satura
 
 
 def speckle_stats_batch(tb, *, groups: set, tiles: bool = True, saturation_value: float | None = 65535.0, eps: float = 1e-6,
-                        keep_autocorr: bool = True) -> list[dict]:
+                        keep_autocorr: bool = True, autocorr_out: np.ndarray | None = None) -> list[dict]:
     """{"full": ..., "tiles": ...} of every frame of a (B, H, W) device stack (already in display orientation): the
     arithmetic of speckle_stats with every kernel launched once per batch and tile shape instead of once per frame and
     tile.  Used by speckle_stack_stats; equal to the per-frame function (tests/test_gpu_metrics.py)."""
@@ -334,10 +334,16 @@ def speckle_stats_batch(tb, *, groups: set, tiles: bool = True, saturation_value
         ac = _corr.autocorr2d_stack(sq, remove_mean=True, standardize=False, normalize="peak", return_tensors=True)
         n_sq = int(sq.shape[1])
         xlag = (np.arange(n_sq) - n_sq // 2).astype(float)
-        ac_host = D.to_host(ac, np.float64) if keep_autocorr else None
+        if autocorr_out is not None:     # (B, n, n) float64 slice of the caller's (T, n, n) result: converted on the device, one copy
+            import torch
+
+            torch.from_numpy(autocorr_out).copy_(ac.double())
+            ac_host = autocorr_out
+        else:
+            ac_host = D.to_host(ac, np.float64) if keep_autocorr else None
         for f, (lx, ly, leq) in enumerate(_widths_batch(ac, 1.0 / np.e)):
             g = {"lx": lx, "ly": ly, "leq": float(leq), "r": float(lx / ly) if ly != 0 else float("inf")}
-            if keep_autocorr:
+            if ac_host is not None:
                 g.update({"autocorr": ac_host[f], "xlag": xlag, "ylag": xlag.copy()})
             outs[f]["full"]["grain"] = g
     if "stats" in groups:
@@ -454,12 +460,20 @@ def speckle_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "al
     dev_all, _, _ = D.to_device_f32(stack, ndim=(3,))
     fb = max(1, min(T, (256 << 20) // (4 * H * W)))     # frames per batch: <= 256 MiB of pixels
     per_frame = []
+    n_sq = max(H, W)
+    ac_all = np.empty((T, n_sq, n_sq), dtype=np.float64) if "grain" in groups else None   # full.grain.autocorr, as the reference stacks it
     for a in range(0, T, fb):
         tb = dev_all[a:a + fb]
         if lower:                                       # apply_display_origin (common.py:44-72): rows flipped before the metrics
             tb = tb.flip(1).contiguous()
-        per_frame.extend(speckle_stats_batch(tb, groups=groups, tiles=tiles, saturation_value=saturation_value, eps=eps))
+        per_frame.extend(speckle_stats_batch(tb, groups=groups, tiles=tiles, saturation_value=saturation_value, eps=eps,
+                                             autocorr_out=None if ac_all is None else ac_all[a:a + fb]))
+    if ac_all is not None:
+        for d in per_frame:
+            d["full"]["grain"].pop("autocorr")
     out_full = stack_time_series([d["full"] for d in per_frame])
+    if ac_all is not None:
+        out_full["grain"]["autocorr"] = ac_all
     out_tiles = None
     if tiles and all(isinstance(d.get("tiles"), dict) for d in per_frame):
         out_tiles = stack_time_series([d["tiles"] for d in per_frame])
