@@ -256,3 +256,22 @@ def test_sharded_tracking_equals_single_rank(gs):
     tr = sharded.track_stack_sharded(stack, big, frame0=stack[0], prev=stack[0], subpixel=False)
     assert np.array_equal(tr["dy_abs"][:, 0], sh[:, 0]) and np.array_equal(tr["dx_abs"][:, 0], sh[:, 1])
     assert np.array_equal(tr["dy_inc"][1:, 0], np.diff(sh[:, 0])) and np.array_equal(tr["dx_inc"][1:, 0], np.diff(sh[:, 1]))
+
+
+def test_template_matching_mixed_template_sizes(gs):
+    """One batched call with templates of different shapes (every pair has its own match-map geometry)."""
+    from barc4dip_amd import synth
+    from oracle import ncc_np as N
+
+    stack, sh = synth.shifted_stack(3, 256, seed=21, max_shift=9)
+    rois = [(40, 101, 50, 111), (100, 141, 30, 151), (5, 200, 120, 161)]     # 61x61, 41x121, 195x41
+    pair_img = [t for t in range(3) for _ in rois]
+    pair_tpl = [k for _ in range(3) for k in range(len(rois))]
+    res, pij = gs.template_matching_batch(stack, stack, [0] * len(rois), rois, pair_img, pair_tpl, backend="opencv",
+                                          subpixel=True, return_peak_ij=True)
+    for i, (t, k) in enumerate(zip(pair_img, pair_tpl)):
+        y0, y1, x0, x1 = rois[k]
+        want = N.template_matching(stack[0][y0:y1, x0:x1], stack[t], slices_yx=(slice(y0, y1), slice(x0, x1)), backend="opencv")
+        assert res[i, 0] == pytest.approx(want[0], abs=3e-3) and res[i, 1] == pytest.approx(want[1], abs=3e-3), (t, k)
+        assert res[i, 2] == pytest.approx(want[2], abs=2e-4) and res[i, 3] == pytest.approx(want[3], rel=1e-3)
+        assert (round(res[i, 0]), round(res[i, 1])) == (sh[t][0], sh[t][1])
