@@ -256,8 +256,10 @@ static int launch_track_fin(const FinArgs& fa, int pairs, hipStream_t st) {
 // Summed-area tables (float64) of the image as the matcher sees it, v = (x - mean) / denom in float32 (raw image:
 // mean 0, denom 1), and of v^2: sat[(y + 1) (nx + 1) + x + 1] = sum over rows <= y, columns <= x.
 // Row pass: grid (ny, nimg), block 256; column pass: grid (ceil((nx + 1) / 64), nimg), block 64.
+// win > 0: the row holds the WINDOW sums H(y, j) = sum_{x = j .. j + win - 1} instead of the prefix (then the column pass
+// yields V(y, j) = sum_{y' < y} H(y', j) and a window sum is V(i + h, j) - V(i, j): two loads instead of four).
 __global__ void __launch_bounds__(256) k_sat_rows(const float* __restrict__ frames, int ny, int nx, const RowSrc* __restrict__ srcs,
-                                                  double* __restrict__ sat1, double* __restrict__ sat2) {
+                                                  double* __restrict__ sat1, double* __restrict__ sat2, int win) {
     __shared__ double s1[256], s2[256];
     const RowSrc sd = srcs[blockIdx.y];
     const int y = blockIdx.x, per = (nx + 255) / 256;
@@ -299,6 +301,33 @@ __global__ void __launch_bounds__(256) k_sat_rows(const float* __restrict__ fram
             sat1[base + x] = 0.0;
             sat2[base + x] = 0.0;
         }
+    if (win > 0) {   // prefix P (o[x] = sum of the first x values) -> window sums, in place: read both ends, barrier, write
+        __threadfence_block();
+        __syncthreads();
+        double pa1[16], pb1[16], pa2[16], pb2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = x0 + k;
+            const bool in = k < per && j < x1, full = in && j + win <= nx;
+            pa1[k] = in ? o1[j] : 0.0;
+            pa2[k] = in ? o2[j] : 0.0;
+            pb1[k] = full ? o1[j + win] : pa1[k];
+            pb2[k] = full ? o2[j + win] : pa2[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = x0 + k;
+            if (k < per && j < x1) {
+                o1[j] = pb1[k] - pa1[k];
+                o2[j] = pb2[k] - pa2[k];
+            }
+        }
+        if (threadIdx.x == 0) {
+            o1[nx] = 0.0;
+            o2[nx] = 0.0;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(64) k_sat_cols(int ny, int nx, double* __restrict__ sat1, double* __restrict__ sat2) {
@@ -353,8 +382,10 @@ __global__ void __launch_bounds__(1024) k_tpl_stats(const float* __restrict__ fr
 
 struct NccArgs {
     const float* xc;      // (pairs, ny, nx) shifted circular cross-correlation sum I[p + d] T[p], d = index - (ny/2, nx/2)
-    const double* sat1;   // (nimg, ny + 1, nx + 1)
+    const double* sat1;   // (nwidths, nimg, ny + 1, nx + 1) column-prefixed window sums (k_sat_rows with win = template width)
     const double* sat2;
+    const int* tpl_widx;  // template -> width slot
+    int nimg;
     const int* pair_img;
     const int* pair_tpl;
     const RowSrc* tsrc;   // template descriptors (ROI = reference position)
@@ -378,8 +409,9 @@ __global__ void __launch_bounds__(256) k_ncc_map(NccArgs p) {
     const int h = ts.y1 - ts.y0, w = ts.x1 - ts.x0, hv = p.img_h - h + 1, wv = p.img_w - w + 1, n = hv * wv;
     const double tmean = p.tstat[2 * p.pair_tpl[pair]], tssd = p.tstat[2 * p.pair_tpl[pair] + 1], vol = (double)h * w;
     const size_t W1 = (size_t)p.nx + 1, fpix = (size_t)p.ny * p.nx;
-    const double* s1 = p.sat1 + (size_t)p.pair_img[pair] * (p.ny + 1) * W1;
-    const double* s2 = p.sat2 + (size_t)p.pair_img[pair] * (p.ny + 1) * W1;
+    const size_t slot = (size_t)p.tpl_widx[p.pair_tpl[pair]] * p.nimg + p.pair_img[pair];
+    const double* s1 = p.sat1 + slot * (p.ny + 1) * W1;
+    const double* s2 = p.sat2 + slot * (p.ny + 1) * W1;
     const float* xc = p.xc + pair * fpix;
     const int per = (n + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * per, e1 = min(n, e0 + per);
     float bv = -INFINITY;
@@ -387,8 +419,8 @@ __global__ void __launch_bounds__(256) k_ncc_map(NccArgs p) {
     for (int e = e0 + threadIdx.x; e < e1; e += 256) {
         const int i = e / wv, j = e % wv;
         const size_t a = (size_t)i * W1 + j, b = (size_t)(i + h) * W1 + j;
-        const double S1 = s1[b + w] - s1[a + w] - s1[b] + s1[a];
-        const double S2 = s2[b + w] - s2[a + w] - s2[b] + s2[a];
+        const double S1 = s1[b] - s1[a];
+        const double S2 = s2[b] - s2[a];
         const int yy = (p.ny / 2 + i - ts.y0) & (p.ny - 1), xx = (p.nx / 2 + j - ts.x0) & (p.nx - 1);
         const double num = (double)xc[(size_t)yy * p.nx + xx] - S1 * tmean;
         const double den = sqrt(fmax((S2 - S1 * S1 / vol) * tssd, 0.0));
@@ -898,8 +930,18 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     add(sizeof(RowSrc) * nsrc);
     add(sizeof(double) * 2 * ROI_SPLIT * nsrc);
     add(sizeof(int) * 3 * (size_t)npairs);
-    add(sizeof(double) * satn * nimg);
-    add(sizeof(double) * satn * nimg);
+    std::vector<int> widths, widx(ntpl);   // distinct template widths: one pair of window-sum tables per (width, image)
+    for (int k = 0; k < ntpl; ++k) {
+        const int w = tpl_roi[4 * k + 3] - tpl_roi[4 * k + 2];
+        size_t j = 0;
+        while (j < widths.size() && widths[j] != w) ++j;
+        if (j == widths.size()) widths.push_back(w);
+        widx[k] = (int)j;
+    }
+    const size_t nw = widths.size();
+    add(sizeof(double) * satn * nimg * nw);
+    add(sizeof(double) * satn * nimg * nw);
+    add(sizeof(int) * (size_t)ntpl);
     add(sizeof(double) * 2 * (size_t)ntpl);
     add(sizeof(float2) * half * pc);
     add(sizeof(float) * (size_t)ny * pc);
@@ -917,8 +959,9 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     double* roi_part = ar.take<double>((size_t)2 * ROI_SPLIT * nsrc);
     int* pidx = ar.take<int>(3 * (size_t)npairs);
     int* sidx = pidx + 2 * (size_t)npairs;
-    double* sat1 = ar.take<double>(satn * nimg);
-    double* sat2 = ar.take<double>(satn * nimg);
+    double* sat1 = ar.take<double>(satn * nimg * nw);
+    double* sat2 = ar.take<double>(satn * nimg * nw);
+    int* d_widx = ar.take<int>((size_t)ntpl);
     double* tstat = ar.take<double>(2 * (size_t)ntpl);
     float2* g = ar.take<float2>(half * pc);
     float* gnyq = ar.take<float>((size_t)ny * pc);
@@ -941,13 +984,17 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     }
     B4D_HIP(hipMemcpyAsync(srcs, h.data(), sizeof(RowSrc) * nsrc, hipMemcpyHostToDevice, st));
     B4D_HIP(hipMemcpyAsync(pidx, hp.data(), sizeof(int) * hp.size(), hipMemcpyHostToDevice, st));
+    B4D_HIP(hipMemcpyAsync(d_widx, widx.data(), sizeof(int) * ntpl, hipMemcpyHostToDevice, st));
     B4D_HIP(hipStreamSynchronize(st));
     // "opencv": the image is z-scored as a whole (tracking.py:157); "skimage": raw float32 image (tracking.py:166)
     if (zscore_image && (rc = roi_stats(images, ny, nx, eps, srcs, nimg, roi_part, st))) return rc;
     if ((rc = roi_stats(tpl_src, ny, nx, eps, srcs + nimg, ntpl, roi_part + (size_t)2 * ROI_SPLIT * nimg, st))) return rc;
     hipLaunchKernelGGL(k_tpl_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, srcs + nimg, tstat);
-    hipLaunchKernelGGL(k_sat_rows, dim3(ny, nimg), dim3(256), 0, st, images, ny, nx, srcs, sat1, sat2);
-    hipLaunchKernelGGL(k_sat_cols, dim3((nx + 64) / 64, nimg), dim3(64), 0, st, ny, nx, sat1, sat2);
+    for (size_t j = 0; j < nw; ++j) {
+        hipLaunchKernelGGL(k_sat_rows, dim3(ny, nimg), dim3(256), 0, st, images, ny, nx, srcs, sat1 + j * satn * nimg, sat2 + j * satn * nimg,
+                           widths[j]);
+        hipLaunchKernelGGL(k_sat_cols, dim3((nx + 64) / 64, nimg), dim3(64), 0, st, ny, nx, sat1 + j * satn * nimg, sat2 + j * satn * nimg);
+    }
     B4D_HIP(hipGetLastError());
     const int fc = std::max(1, pl->chunk * 2);
     for (int i0 = 0; i0 < nimg; i0 += fc) {
@@ -982,6 +1029,8 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
             na.pair_tpl = pidx + npairs + p0;
             na.tsrc = srcs + nimg;
             na.tstat = tstat;
+            na.tpl_widx = d_widx;
+            na.nimg = nimg;
             na.ncc = ncc;
             na.absncc = absncc;
             na.part_val = pval;
@@ -996,6 +1045,7 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
             FinArgs fa{};
             fa.mag = ncc;
             fa.med_src = absncc;
+            fa.compact = xc;          // the correlation maps are consumed: their buffer serves as the median's scratch
             fa.geom = geom;
             fa.stride = fpix;
             fa.part_val = pval;
