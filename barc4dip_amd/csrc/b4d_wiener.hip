@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) k_pm_pre(const void* __restrict__ xin, fl
 //       2 the pair's half spectra Fa, Fb (k = 0 .. io.half - 1) unpacked to half rows 2 s, 2 s + 1
 //       3 as 1 for the pair: real part -> row 2 s, imaginary part -> row 2 s + 1
 // grid (S), block FT, dynamic LDS (2 N + A + B) complex values.
-constexpr int FT = 1024;
+constexpr int FT_MAX = 1024, FT_ONEBUF = 512;
 // acc += x * w (complex) in two packed FMAs
 __device__ __forceinline__ v2f cmac(v2f acc, v2f x, v2f w) {
     v2f t, r;
@@ -75,9 +75,16 @@ __device__ __forceinline__ v2f cmac(v2f acc, v2f x, v2f w) {
 }
 // complex LDS words of one row transform: two row buffers + the small-DFT tables (full A x A / B x B matrices, padded to
 // multiples of 4 columns, when both factors are <= 32; otherwise the A + B roots of unity)
-__host__ __device__ inline size_t pm_lds_elems(int P, int A, int B) {
+__host__ __device__ inline size_t pm_lds_elems(int P, int A, int B, bool onebuf = false) {
     const size_t tabs = (A <= 32 && B <= 32) ? (size_t)A * ((A + 3) & ~3) + (size_t)B * ((B + 3) & ~3) : (size_t)A + B;
-    return 2 * (size_t)P * A * B + tabs;
+    return (onebuf ? 1 : 2) * (size_t)P * A * B + tabs;
+}
+// one-buffer mode: blocked small DFTs whose item counts fit one round of FT_ONEBUF lanes (measured: 2560 = 16 * 16 * 10
+// gains 1.5x from three workgroups per CU; 4104 = 8 * 27 * 19 with 560 items is faster on two 1024-lane workgroups)
+inline bool pm_onebuf(int P, int A, int B) {
+    if (!(A <= 32 && B <= 32)) return false;
+    const int Ap = (A + 3) & ~3, Bp = (B + 3) & ~3;
+    return P * (Ap / 4) * ((B + 1) / 2) <= FT_ONEBUF && P * ((A + 1) / 2) * (Bp / 4) <= FT_ONEBUF;
 }
 struct FusedIO {
     const float* frame;   // IN 2 / OUT 1: the (h, w) frame read / written
@@ -87,14 +94,18 @@ struct FusedIO {
     int half, rows;       // pair modes: half-row length N/2 + 1 and the number of (padded) rows
 };
 
-template <int P, int IN, int OUT>
-__global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, float2* __restrict__ out, const float2* __restrict__ twN,
+template <int P, int IN, int OUT, bool ONEBUF>
+__global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const void* __restrict__ xin, float2* __restrict__ out, const float2* __restrict__ twN,
                                                  int A, int B, const float2* __restrict__ filt, int conj_io, float scale, FusedIO io) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr bool onebuf = ONEBUF;
+    constexpr int FT = ONEBUF ? FT_ONEBUF : FT_MAX;
     const int M = A * B, N = P * M;
+    // onebuf (small item counts): every lane owns at most one item of the two small-DFT phases, keeps its outputs in
+    // registers across a barrier and writes them back into the SAME row buffer: half the LDS, three workgroups per CU
     float2* buf0 = sm;
-    float2* buf1 = sm + N;
-    float2* tabA = buf1 + N;
+    float2* buf1 = onebuf ? sm : sm + N;
+    float2* tabA = sm + (onebuf ? N : 2 * N);
     const bool blocked = A <= 32 && B <= 32;   // full small-DFT matrices in LDS, 4 x 2 register blocks, packed FMAs
     const int Ap = (A + 3) & ~3, Bp = (B + 3) & ~3;
     float2* tabB = tabA + (blocked ? A * Ap : A);
@@ -163,6 +174,40 @@ __global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, f
     __syncthreads();
     // ---- DFT_A over a (n2 = B a + b), then the twiddle W_M^{b c} = W_N^{P b c}
 #ifndef B4D_EXP_PM_SKIP23
+    if (onebuf) {    // one item per lane: compute into registers, barrier, write back into the same buffer
+        const int nCB = Ap / 4, nBB = (B + 1) / 2;
+        const bool act = (int)threadIdx.x < P * nCB * nBB;
+        const int it = act ? threadIdx.x : 0;
+        const int bb = it % nBB, r = it / nBB, c0 = (r % nCB) * 4, k1 = r / nCB;
+        const int b0 = 2 * bb, b1 = min(b0 + 1, B - 1);
+        v2f acc[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = v2f{0.f, 0.f};
+        if (act) {
+            const float2* src = buf0 + k1 * M;
+            const float4* wrow = reinterpret_cast<const float4*>(tabA + c0);
+            for (int a = 0; a < A; ++a) {
+                const v2f x0 = to_v(src[B * a + b0]), x1 = to_v(src[B * a + b1]);
+                const float4 wa = wrow[a * (Ap / 2)], wb = wrow[a * (Ap / 2) + 1];
+                const v2f w[4] = {v2f{wa.x, wa.y}, v2f{wa.z, wa.w}, v2f{wb.x, wb.y}, v2f{wb.z, wb.w}};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][0] = cmac(acc[j][0], x0, w[j]);
+                    acc[j][1] = cmac(acc[j][1], x1, w[j]);
+                }
+            }
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                if (c >= A) continue;
+                buf0[k1 * M + c * B + b0] = cmulf(to_f(acc[j][0]), twN[(size_t)P * b0 * c]);
+                if (b0 + 1 < B) buf0[k1 * M + c * B + b0 + 1] = cmulf(to_f(acc[j][1]), twN[(size_t)P * (b0 + 1) * c]);
+            }
+        }
+    } else
     if (blocked) {   // item = (k1, 4 outputs c, 2 columns b): per a two x reads and one 4-wide table row feed 8 complex MACs
         const int nCB = Ap / 4, nBB = (B + 1) / 2;
         for (int it = threadIdx.x; it < P * nCB * nBB; it += FT) {
@@ -232,6 +277,41 @@ __global__ void __launch_bounds__(FT) k_pm_fused(const void* __restrict__ xin, f
         }
     __syncthreads();
     // ---- DFT_B over b (k2 = c + A d) -> natural order k = k1 + P (c + A d) in buf0
+    if (onebuf) {
+        const int nCP = (A + 1) / 2, nDB = Bp / 4;
+        const bool act = (int)threadIdx.x < P * nCP * nDB;
+        const int it = act ? threadIdx.x : 0;
+        const int cp = it % nCP, r = it / nCP, d0 = (r % nDB) * 4, k1 = r / nDB;
+        const int c0 = 2 * cp, c1 = min(c0 + 1, A - 1);
+        v2f acc[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = v2f{0.f, 0.f};
+        if (act) {
+            const float2* s0 = buf0 + k1 * M + c0 * B;
+            const float2* s1 = buf0 + k1 * M + c1 * B;
+            const float4* wrow = reinterpret_cast<const float4*>(tabB + d0);
+            for (int b = 0; b < B; ++b) {
+                const v2f x0 = to_v(s0[b]), x1 = to_v(s1[b]);
+                const float4 wa = wrow[b * (Bp / 2)], wb = wrow[b * (Bp / 2) + 1];
+                const v2f w[4] = {v2f{wa.x, wa.y}, v2f{wa.z, wa.w}, v2f{wb.x, wb.y}, v2f{wb.z, wb.w}};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][0] = cmac(acc[j][0], x0, w[j]);
+                    acc[j][1] = cmac(acc[j][1], x1, w[j]);
+                }
+            }
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = d0 + j;
+                if (d >= B) continue;
+                buf0[k1 + P * (c0 + A * d)] = to_f(acc[j][0]);
+                if (c0 + 1 < A) buf0[k1 + P * (c0 + 1 + A * d)] = to_f(acc[j][1]);
+            }
+        }
+    } else
     if (blocked) {   // item = (k1, 2 rows c, 4 outputs d)
         const int nCP = (A + 1) / 2, nDB = Bp / 4;
         for (int it = threadIdx.x; it < P * nCP * nDB; it += FT) {
@@ -545,15 +625,22 @@ static void split_ab(int P, int M, int* A, int* B) {
 template <int P, int IN, int OUT>
 static int pm_fused_launch2(const void* x, float2* out, const float2* tw, int A, int B, int S, const float2* filt, int conj_io, float scale,
                             const FusedIO& io, hipStream_t st) {
-    const size_t lds = sizeof(float2) * pm_lds_elems(P, A, B);
+    const bool onebuf = pm_onebuf(P, A, B);
+    const size_t lds = sizeof(float2) * pm_lds_elems(P, A, B, onebuf);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_fused<P, IN, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_fused<P, IN, OUT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        150 * 1024);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_fused<P, IN, OUT, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     });
     B4D_HIP(attr_err);
-    hipLaunchKernelGGL((k_pm_fused<P, IN, OUT>), dim3(S), dim3(FT), lds, st, x, out, tw, A, B, filt, conj_io, scale, io);
+    if (onebuf)
+        hipLaunchKernelGGL((k_pm_fused<P, IN, OUT, true>), dim3(S), dim3(FT_ONEBUF), lds, st, x, out, tw, A, B, filt, conj_io, scale, io);
+    else
+        hipLaunchKernelGGL((k_pm_fused<P, IN, OUT, false>), dim3(S), dim3(FT_MAX), lds, st, x, out, tw, A, B, filt, conj_io, scale, io);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
