@@ -60,6 +60,7 @@ SIGNATURES = {
     "b4d_stack_mean_f32": (_i, [_vp, _i, _sz, _vp, _vp]),
     "b4d_flat_den": (_i, [_vp, _vp, _sz, _f, _i, _vp, _vp]),
     "b4d_flat_field": (_i, [_vp, _i, _sz, _vp, _vp, _f, _f, _i, _vp, _vp]),
+    "b4d_to_f32": (_i, [_vp, _i, _sz, _vp, _vp]),
     "b4d_repair_pixels": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "b4d_sta2_eigenvalues": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "b4d_percentiles": (_i, [_vp, _i, _sz, _vp, _i, _vp, _vp]),

@@ -3,6 +3,7 @@
 // the default path is bit-exact against NumPy: out = ((I - D) / (F - D)) * s, zero where F - D <= eps.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <string>
 
 #include "../../include/b4d.h"
@@ -93,6 +94,12 @@ __global__ void __launch_bounds__(256) k_bad_scatter(float* __restrict__ frames,
     frames[(size_t)blockIdx.y * npix + idx[k]] = rep[(size_t)blockIdx.y * nbad + k];
 }
 
+// raw detector words -> float32 (images.astype(np.float32), normalize.py:79 / io): one element per lane, 4 per iteration
+template <typename T>
+__global__ void __launch_bounds__(256) k_to_f32(const T* __restrict__ src, size_t n, float* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+
 }  // namespace b4d
 
 using namespace b4d;
@@ -133,5 +140,23 @@ extern "C" int b4d_repair_pixels(float* frames, int batch, int ny, int nx, const
     hipLaunchKernelGGL(k_bad_scatter, dim3((nbad + 255) / 256, batch), dim3(256), 0, st, frames, (size_t)ny * nx, idx, nbad, rep);
     B4D_HIP(hipGetLastError());
     B4D_HIP(hipStreamSynchronize(st));  // the shared scratch holds the repaired values until the scatter has run
+    return B4D_OK;
+}
+
+extern "C" int b4d_to_f32(const void* src, int dtype, size_t n, float* dst, void* stream) {
+    if (!src || !dst || n < 1) return fail(B4D_EINVAL, "b4d_to_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 65535)), block(256);
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(k_to_f32<unsigned char>, grid, block, 0, st, static_cast<const unsigned char*>(src), n, dst); break;
+        case 1: hipLaunchKernelGGL(k_to_f32<unsigned short>, grid, block, 0, st, static_cast<const unsigned short*>(src), n, dst); break;
+        case 2: hipLaunchKernelGGL(k_to_f32<short>, grid, block, 0, st, static_cast<const short*>(src), n, dst); break;
+        case 3: hipLaunchKernelGGL(k_to_f32<int>, grid, block, 0, st, static_cast<const int*>(src), n, dst); break;
+        case 4: hipLaunchKernelGGL(k_to_f32<unsigned int>, grid, block, 0, st, static_cast<const unsigned int*>(src), n, dst); break;
+        case 5: hipLaunchKernelGGL(k_to_f32<float>, grid, block, 0, st, static_cast<const float*>(src), n, dst); break;
+        case 6: hipLaunchKernelGGL(k_to_f32<double>, grid, block, 0, st, static_cast<const double*>(src), n, dst); break;
+        default: return fail(B4D_EINVAL, "b4d_to_f32: dtype code must be 0..6 (u8, u16, i16, i32, u32, f32, f64)");
+    }
+    B4D_HIP(hipGetLastError());
     return B4D_OK;
 }

@@ -154,6 +154,10 @@ int b4d_flat_field(const float* frames, int batch, size_t npix, const float* fla
                    int apply_scale, float* out, void* stream);
 int b4d_repair_pixels(float* frames, int batch, int ny, int nx, const long long* idx, int nbad, void* stream);
 
+/* images.astype(np.float32) on the device for raw detector words staged through pinned memory (barc4dip_amd/ingest.py):
+ * dtype 0 u8, 1 u16, 2 i16, 3 i32, 4 u32, 5 f32, 6 f64.  src / dst: DEVICE, n elements. */
+int b4d_to_f32(const void* src, int dtype, size_t n, float* dst, void* stream);
+
 /* metrics/sharpness.py:752-861 eigenvalues (STA2): J = (x - mean(x)) / ||x||_2, eig_i = s_i(J)^2 / (M N - 1).
  * The reference takes every singular value from LAPACK and uses the first k (default 5); this returns the leading
  * nout (<= 8) of them, descending, from the Gram matrix of the smaller side (MFMA) and a 32-vector block subspace

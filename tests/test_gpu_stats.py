@@ -70,3 +70,26 @@ def test_temporal_stats_vs_oracle():
     K.temporal_accumulate(dev, s[0], s[1])
     sx, sxx, n = Tn.temporal_sums(stack)
     assert np.array_equal(s[0].cpu().numpy(), sx) and np.array_equal(s[1].cpu().numpy(), sxx)
+
+
+def test_streamed_ingest_equals_resident(tmp_path):
+    """iter_device_chunks / temporal_stats_streamed (pinned double buffering, side copy stream) over a memory-mapped
+    uint16 .npy file give the bits of the device-resident path; ragged last chunk, chunk > T and chunk = 1 included."""
+    import torch
+
+    from barc4dip_amd import ingest, synth
+    from barc4dip_amd.metrics import temporal_stats
+
+    stack = np.stack([synth.speckle_frame(128, 400 + i) for i in range(11)]).astype(np.uint16)
+    path = tmp_path / "stack.npy"
+    np.save(path, stack)
+    mm = np.load(path, mmap_mode="r")
+    want = temporal_stats(stack.astype(np.float32))
+    for chunk in (4, 1, 64):
+        got = ingest.temporal_stats_streamed(mm, chunk_frames=chunk)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        seen = [c.clone() for c in ingest.iter_device_chunks(mm, chunk)]
+        assert torch.equal(torch.cat(seen), torch.from_numpy(stack.astype(np.float32)).cuda())
+    with pytest.raises(ValueError):
+        list(ingest.iter_device_chunks(stack[0], 4))
