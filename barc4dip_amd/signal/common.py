@@ -1,65 +1,63 @@
-"""Axis / calibration validation shared by fft.py and corr.py (host side, NumPy).
+"""Calibration of sampling axes for the host side of fft.py / corr.py.
 
-Mirrors the argument rules of the reference (signal/common.py:13-90): give either the pixel
-steps (dx, dy) or uniformly sampled axes (x, y), never both; steps must be positive.
+Contract taken from the reference's argument rules (signal/common.py:13-90): a transform is calibrated EITHER by pixel
+steps (dx, dy > 0) OR by explicit, uniformly sampled coordinate axes, never by both; every violation is a ValueError.
 """
 from __future__ import annotations
 
 import numpy as np
 
+_UNIFORMITY_TOL = 1e-6      # largest relative spread of the sample spacing still called "uniform"
 
-def _uniform_step(axis, name: str) -> float:
-    a = np.asarray(axis, dtype=float)
-    if a.ndim != 1 or a.size < 2:
-        raise ValueError(f"{name} must be a 1D array with at least 2 samples.")
-    steps = np.diff(a)
-    if not np.all(np.isfinite(steps)):
-        raise ValueError(f"{name} contains non-finite values.")
-    if not (np.all(steps > 0) or np.all(steps < 0)):
-        raise ValueError(f"{name} must be strictly monotonic (uniform sampling assumed).")
-    mag = np.abs(steps)
-    step = float(np.median(mag))
-    if step <= 0:
-        raise ValueError(f"{name} has non-positive sampling step.")
-    dev = float(np.max(np.abs(mag - step)) / step)
-    if dev > 1e-6:
-        raise ValueError(f"{name} appears non-uniform (max relative deviation {dev:.2e}).")
-    return step
+
+def _axis_step(axis, expected_size: int | None, label: str) -> float:
+    """Spacing of an explicit coordinate axis after checking shape, length, finiteness, monotony and uniformity."""
+    coords = np.asarray(axis, dtype=float)
+    problems = None
+    if coords.ndim != 1:
+        problems = "be one-dimensional"
+    elif coords.size < 2:
+        problems = "hold at least two samples"
+    elif expected_size is not None and coords.size != expected_size:
+        problems = f"have {expected_size} samples, one per pixel"
+    if problems:
+        raise ValueError(f"axis {label!r} must {problems}.")
+    gaps = np.diff(coords)
+    if not np.isfinite(gaps).all():
+        raise ValueError(f"axis {label!r} has NaN or infinite coordinates.")
+    if not ((gaps > 0).all() or (gaps < 0).all()):
+        raise ValueError(f"axis {label!r} is not strictly monotonic.")
+    spacing = np.abs(gaps)
+    typical = float(np.median(spacing))
+    spread = float(np.abs(spacing - typical).max() / typical) if typical > 0 else np.inf
+    if not spread <= _UNIFORMITY_TOL:
+        raise ValueError(f"axis {label!r} is not uniformly sampled (relative spread {spread:.1e}).")
+    return typical
+
+
+def _pick_step(axis, step: float, expected_size: int | None, label: str) -> float:
+    """One axis: the explicit coordinates win if given (then the step must be left at its default)."""
+    if axis is None:
+        if not step > 0:
+            raise ValueError(f"the pixel step d{label} must be positive.")
+        return float(step)
+    if step != 1.0:
+        raise ValueError(f"calibrate axis {label!r} with coordinates or with d{label}, not with both.")
+    return _axis_step(axis, expected_size, label)
 
 
 def _resolve_step_1d(*, n: int, x, dx: float, name: str) -> float:
-    if x is not None and dx != 1.0:
-        raise ValueError(f"Provide either {name} or d{name}, not both.")
-    if x is None:
-        if dx <= 0:
-            raise ValueError(f"d{name} must be > 0.")
-        return float(dx)
-    x = np.asarray(x, dtype=float)
-    if x.ndim != 1:
-        raise ValueError(f"{name} must be a 1D array.")
-    if x.size != n:
-        raise ValueError(f"{name}.size must match the signal length ({n}).")
-    return _uniform_step(x, name)
+    return _pick_step(x, dx, int(n), name)
 
 
 def _resolve_steps_2d(*, shape, x, y, dx: float, dy: float) -> tuple[float, float]:
-    ny, nx = shape
-    if (x is None) != (y is None):
-        raise ValueError("Provide both x and y axes, or neither.")
-    if (x is not None and dx != 1.0) or (y is not None and dy != 1.0):
-        raise ValueError("Provide either (x, y) or (dx, dy), not both.")
-    if x is None:
-        if dx <= 0 or dy <= 0:
-            raise ValueError("dx and dy must be > 0.")
-        return float(dx), float(dy)
-    x = np.asarray(x, dtype=float)
-    y = np.asarray(y, dtype=float)
-    if x.ndim != 1 or y.ndim != 1:
-        raise ValueError("x and y must be 1D arrays.")
-    if x.size != nx or y.size != ny:
-        raise ValueError("x/y sizes must match (nx, ny) of the image.")
-    return _uniform_step(x, "x"), _uniform_step(y, "y")
+    rows, cols = (int(v) for v in shape)
+    if (x is None) ^ (y is None):
+        raise ValueError("explicit axes come in pairs: give x and y together, or neither.")
+    return _pick_step(x, dx, cols, "x"), _pick_step(y, dy, rows, "y")
 
 
 def _lag_axis_from_step(n: int, step: float) -> np.ndarray:
-    return (np.arange(n, dtype=float) - (n // 2)) * float(step)
+    """Lag coordinates centred on n // 2 (zero lag at the fftshift-ed centre)."""
+    centre = n // 2
+    return float(step) * (np.arange(n, dtype=float) - centre)
