@@ -300,3 +300,18 @@ def test_complex_fft2d_and_ifft2d(gs, shape):
     assert nerr(gs.fft.ifft2d(Fr), S.ifft2d(Fr)) < TOL and gs.fft.ifft2d(Fr).dtype == np.complex128
     real = rng.random(shape).astype(np.float32)
     assert nerr(gs.fft.ifft2d(gs.fft2d(real)[0]).real, real) < TOL
+
+
+@pytest.mark.parametrize("shape", [(1072, 536), (1197, 640), (1540, 1326), (1326, 1072), (3000, 520), (8192, 64)])
+def test_fused_transform_factorisations(gs, shape):
+    """Sides chosen for the corner cases of the fused row transform: a prime M (1072 = 16 * 67: A = 67, B = 1, table-free
+    path), P = 1 with A > 32 (1197 = 63 * 19), three-level splits (1540 = 4 * 35 * 11, 1326 = 2 * 39 * 17), the one-buffer
+    variant (536, 640, 520) next to the two-buffer one, and the longest supported row (8192)."""
+    from oracle import signal_np as S
+
+    rng = np.random.default_rng(shape[0] ^ shape[1])
+    img = (rng.random(shape) * 100).astype(np.float32)
+    r64 = img.astype(np.float64)
+    assert nerr(gs.fft2d(img)[0], S.fft2d(r64)[0]) < TOL
+    ac = gs.autocorr2d(img)[0]
+    assert nerr(ac, S.autocorr2d(r64)[0]) < TOL and ac[shape[0] // 2, shape[1] // 2] == 1.0
