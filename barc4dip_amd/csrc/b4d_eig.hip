@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -429,6 +430,68 @@ __global__ void __launch_bounds__(1024) k_ritz(const double* __restrict__ partT,
     }
 }
 
+// ---- small frames (min side < 64: the 32-vector subspace would be most of the matrix): every eigenvalue of the
+// m x m Gram matrix by parallel cyclic Jacobi in float64 (64 x 64 padded with zeros; 32 disjoint rotations per round,
+// row phase then column phase), leading 8 written descending.  grid (batch), block 1024, dynamic LDS 2 * 64 * 65 doubles.
+constexpr int JS = 64;
+__global__ void __launch_bounds__(1024) k_jacobi_small(const float* __restrict__ G, int m, double* __restrict__ ev) {
+    extern __shared__ double jsm[];
+    double(*A0)[JS + 1] = reinterpret_cast<double(*)[JS + 1]>(jsm);
+    double(*A1)[JS + 1] = reinterpret_cast<double(*)[JS + 1]>(jsm + JS * (JS + 1));
+    __shared__ double cs[JS], sg[JS];
+    __shared__ int partner[JS];
+    const float* g = G + (size_t)blockIdx.x * m * m;
+    for (int e = threadIdx.x; e < JS * JS; e += 1024) {
+        const int p = e / JS, q = e % JS;
+        A0[p][q] = (p < m && q < m) ? 0.5 * ((double)g[p * m + q] + (double)g[q * m + p]) : 0.0;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 12; ++sweep)
+        for (int r = 0; r < JS - 1; ++r) {
+            if (threadIdx.x < JS / 2) {
+                const int i = threadIdx.x;
+                const int a = i == 0 ? r : (r + i) % (JS - 1);
+                const int b = i == 0 ? JS - 1 : (r - i + JS - 1) % (JS - 1);
+                const int pp = min(a, b), qq = max(a, b);
+                const double app = A0[pp][pp], aqq = A0[qq][qq], apq = A0[pp][qq];
+                double c = 1.0, s_ = 0.0;
+                if (fabs(apq) > 1e-18 * (fabs(app) + fabs(aqq)) && fabs(apq) > 1e-300) {
+                    const double theta = (aqq - app) / (2.0 * apq);
+                    const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(tt * tt + 1.0);
+                    s_ = tt * c;
+                }
+                cs[pp] = c;
+                cs[qq] = c;
+                sg[pp] = -s_;
+                sg[qq] = s_;
+                partner[pp] = qq;
+                partner[qq] = pp;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < JS * JS; e += 1024) {
+                const int p = e / JS, q = e % JS;
+                A1[p][q] = cs[p] * A0[p][q] + sg[p] * A0[partner[p]][q];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < JS * JS; e += 1024) {
+                const int p = e / JS, q = e % JS;
+                A0[p][q] = cs[q] * A1[p][q] + sg[q] * A1[p][partner[q]];
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x < JS) {
+        const int p = threadIdx.x;
+        const double d = p < m ? A0[p][p] : -1e300;   // padding never ranks among the eigenvalues
+        int rank = 0;
+        for (int j = 0; j < JS; ++j) {
+            const double e = j < m ? A0[j][j] : -1e300;
+            rank += (e > d || (e == d && j < p)) ? 1 : 0;
+        }
+        if (rank < 8) ev[(size_t)blockIdx.x * 8 + rank] = p < m ? d : 0.0;
+    }
+}
+
 }  // namespace b4d
 
 using namespace b4d;
@@ -440,8 +503,51 @@ extern "C" int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int 
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)ny * nx;
     const int m = std::min(ny, nx);
-    if (m < 2 * NB) return fail(B4D_ESIZE, "b4d_sta2_eigenvalues needs min(ny, nx) >= 64");
     const int nblk = (int)std::min<size_t>(64, (npix + 1023) / 1024);
+    if (m < 2 * NB) {   // small frames: all eigenvalues of the m x m Gram matrix by Jacobi
+        size_t sb = 0;
+        auto tk = [&](size_t b) {
+            const size_t o = sb;
+            sb += (b + 255) & ~(size_t)255;
+            return o;
+        };
+        const size_t oJ = tk(sizeof(float) * npix * batch), oG = tk(sizeof(float) * (size_t)m * m * batch);
+        const size_t oP = tk(sizeof(double) * (size_t)nblk * 3 * batch), oE = tk(sizeof(double) * 8 * batch), oS = tk(sizeof(double) * 3 * batch);
+        void* ws = nullptr;
+        int rc = get_scratch(sb, &ws);
+        if (rc) return rc;
+        char* base = static_cast<char*>(ws);
+        float* J = reinterpret_cast<float*>(base + oJ);
+        float* G = reinterpret_cast<float*>(base + oG);
+        double* part = reinterpret_cast<double*>(base + oP);
+        double* evd = reinterpret_cast<double*>(base + oE);
+        double* stat = reinterpret_cast<double*>(base + oS);
+        hipLaunchKernelGGL(k_sta2_sums, dim3(nblk, batch), dim3(1024), 0, st, frames, npix, part);
+        hipLaunchKernelGGL(k_sta2_norm, dim3((unsigned)((npix + 255) / 256), batch), dim3(256), 0, st, frames, npix, part, nblk, J, stat);
+        GramArgs g{J, G, m, ny <= nx ? nx : ny, ny <= nx ? (long long)nx : 1LL, ny <= nx ? 1LL : (long long)nx, (long long)npix, (long long)m * m};
+        hipLaunchKernelGGL(k_gram_mfma, dim3(1, 1, batch), dim3(256), 0, st, g);
+        B4D_HIP(hipMemsetAsync(evd, 0, sizeof(double) * 8 * batch, st));
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        const size_t lds = sizeof(double) * 2 * JS * (JS + 1);
+        std::call_once(once, [&] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+        B4D_HIP(attr_err);
+        hipLaunchKernelGGL(k_jacobi_small, dim3(batch), dim3(1024), lds, st, G, m, evd);
+        B4D_HIP(hipGetLastError());
+        std::vector<double> cur((size_t)batch * 8), hstat((size_t)3 * batch);
+        B4D_HIP(hipMemcpyAsync(cur.data(), evd, sizeof(double) * cur.size(), hipMemcpyDeviceToHost, st));
+        B4D_HIP(hipMemcpyAsync(hstat.data(), stat, sizeof(double) * hstat.size(), hipMemcpyDeviceToHost, st));
+        B4D_HIP(hipStreamSynchronize(st));
+        const double denom = (double)npix - 1.0;
+        for (int b = 0; b < batch; ++b)
+            for (int k = 0; k < nout; ++k) {
+                const bool ok = hstat[(size_t)b * 3 + 2] == 0.0 && hstat[(size_t)b * 3 + 1] > 0.0 && denom > 0.0;
+                out_host[(size_t)b * nout + k] = ok ? std::max(cur[(size_t)b * 8 + k], 0.0) / denom : std::nan("");
+            }
+        return B4D_OK;
+    }
     const int nsplit = std::max(1, std::min(16, m / 128));
     size_t bytes = 0;
     auto take = [&](size_t b) {

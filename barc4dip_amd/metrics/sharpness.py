@@ -1,9 +1,9 @@
 """Sharpness metrics on the GPU -- drop-in for ``barc4dip.metrics.sharpness`` (sharpness.py:89-861).
 
 Tenengrad and Laplacian variance use a fused 3x3 stencil + reduction kernel with scipy's "reflect" borders;
-spectral entropy and the inverse autocorrelation widths reuse the FFT pipeline; STA2 eigenvalues call the
-device SVD of torch.linalg (rocSOLVER) in float64 -- a library call kept until the Gram/eigen kernel of
-SURVEY.md §7 step 8 exists.  Tile policy as in speckles.py.
+spectral entropy and the inverse autocorrelation widths reuse the FFT pipeline; STA2 eigenvalues run on
+b4d_sta2_eigenvalues (Gram matrix on the matrix cores + block subspace iteration).  Tile policy as in
+speckles.py; FFT-based tile metrics and the stack functions are batched per tile shape / over frames.
 """
 from __future__ import annotations
 
@@ -160,20 +160,7 @@ def _sta2_device(stack, nout: int = 8) -> np.ndarray:
     return out
 
 
-_STA2_MIN_SIDE = 64     # below this the 32-vector subspace is most of the matrix: dense device SVD instead
-_STA2_MAX_K = 8
-
-
-def _sta2_svd(stack) -> np.ndarray:
-    """Every eigenvalue of small / wide-k cases from a batched device SVD (rocSOLVER through torch)."""
-    import torch
-
-    x = stack.double()
-    energy = torch.sqrt((x * x).sum(dim=(1, 2), keepdim=True))
-    j = x / energy
-    j = j - j.mean(dim=(1, 2), keepdim=True)
-    s = torch.linalg.svdvals(j)
-    return ((s * s) / float(j[0].numel() - 1)).cpu().numpy()
+_STA2_MAX_K = 8         # leading eigenvalues the kernel returns
 
 
 def _eig_from_svals(eig: np.ndarray, k: int, eps: float) -> dict:
@@ -184,29 +171,27 @@ def _eig_from_svals(eig: np.ndarray, k: int, eps: float) -> dict:
 
 def _eigenvalues_batch(stack, k: int = 5, eps: float = 1e-30) -> list[dict]:
     """STA2 eigenvalues of a (B, h, w) float32 device stack, all frames in one call."""
-    h, w = int(stack.shape[-2]), int(stack.shape[-1])
-    if min(h, w) >= _STA2_MIN_SIDE and int(k) <= _STA2_MAX_K:
-        eig = _sta2_device(stack.contiguous())
-    else:
-        eig = _sta2_svd(stack)
-    return [_eig_from_svals(e, k, eps) for e in eig]
+    if int(k) > _STA2_MAX_K:
+        raise NotImplementedError(f"eigenvalues: k > {_STA2_MAX_K} is not built on the GPU path (the kernel returns the leading "
+                                  f"{_STA2_MAX_K} eigenvalues).")
+    return [_eig_from_svals(e, k, eps) for e in _sta2_device(stack.contiguous())]
 
 
 def eigenvalues(image, *, k: int = 5, eps: float = 1e-30, verbose: bool = False) -> dict:
     """STA2: eig = s^2/(M*N-1) of the energy-normalised, mean-removed image; sum of the first k, e1, e2, e1/e2
     (reference: sharpness.py:752-861).  The leading eigenvalues come from b4d_sta2_eigenvalues (Gram matrix on the
-    matrix cores + block subspace iteration); images under 64 pixels a side or k > 8 take a dense device SVD."""
+    matrix cores + block subspace iteration; a float64 Jacobi on the Gram matrix for images under 64 pixels a side);
+    k <= 8."""
     import torch
 
     t = _check2d(image, "eigenvalues", all_finite=True)
     if int(k) < 1:
         raise ValueError("k must be >= 1.")
-    energy = float(torch.sqrt((t.double() ** 2).sum()))
-    if not np.isfinite(energy) or energy <= 0.0:
-        raise ValueError("eigenvalues cannot normalize an all-zero image.")
     if t.numel() - 1 <= 0:
         raise ValueError("eigenvalues requires at least 2 pixels (M*N >= 2).")
     out = _eigenvalues_batch(t.float().unsqueeze(0), k, eps)[0]
+    if not np.isfinite(out["e1"]):       # the kernel reports frames without energy as NaN rows
+        raise ValueError("eigenvalues cannot normalize an all-zero image.")
     if verbose:
         logger.info("> eigenvalues: %.6g | e1: %.6g | e2: %.6g | e1/e2: %.3f", out["eigenvalues"], out["e1"], out["e2"], out["re"])
     return out
@@ -289,12 +274,11 @@ def sharpness_stats_batch(tb, *, groups: set, tiles: bool = True, saturation_val
         for f, d in enumerate(_inverse_autocorr_width_batch(tb)):
             outs[f]["full"]["autocorrelation"] = d
     if "eigenvalues" in groups:
-        energy = torch.sqrt((tb.double() ** 2).sum(dim=(1, 2)))
-        if not bool((torch.isfinite(energy) & (energy > 0)).all()):
-            raise ValueError("eigenvalues cannot normalize an all-zero image.")
         if h * w - 1 <= 0:
             raise ValueError("eigenvalues requires at least 2 pixels (M*N >= 2).")
         for f, d in enumerate(_eigenvalues_batch(tb.contiguous())):
+            if not np.isfinite(d["e1"]):
+                raise ValueError("eigenvalues cannot normalize an all-zero image.")
             outs[f]["full"]["eigenvalues"] = d
     mode, tile_shape_px = choose_tiling_mode(h, w, tiles=tiles, min_tile_px=128)
     if mode == "off":

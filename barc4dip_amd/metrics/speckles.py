@@ -58,7 +58,7 @@ def _pad_square_dev(t):
     if h == w:
         return t
     n = max(h, w)
-    out = torch.full((n, n), float(t.double().mean()), dtype=torch.float32, device=t.device)
+    out = torch.full((n, n), float(K.moments_batch(_pad4(t[None]), eps=0.0, saturation=None)[0, 1]), dtype=torch.float32, device=t.device)
     y0, x0 = (n - h) // 2, (n - w) // 2
     out[y0:y0 + h, x0:x0 + w] = t
     return out
@@ -121,7 +121,7 @@ def _pad_square_batch(stack):
     if h == w:
         return stack
     n = max(h, w)
-    means = stack.double().mean(dim=(1, 2)).float()
+    means = K.moments_batch(_pad4(stack), eps=0.0, saturation=None)[:, 1].float()     # float64 means from b4d_moments
     out = means[:, None, None].expand(b, n, n).contiguous()
     y0, x0 = (n - h) // 2, (n - w) // 2
     out[:, y0:y0 + h, x0:x0 + w] = stack

@@ -66,9 +66,19 @@ def _flags(remove_mean: bool, normalize: str) -> int:
     return (_ffi.REMOVE_MEAN if remove_mean else 0) | (_ffi.NORM_PEAK if normalize == "peak" else 0)
 
 
+def _frame_variances(t):
+    """Population variance (ddof 0) of every (B, ny, nx) frame from the float64 power sums of b4d_moments -> (B,) float64
+    device tensor (corr.py:229-235 standardises by np.std)."""
+    from ..metrics import kernels as K
+    from ..metrics.speckles import _pad4
+
+    mom = K.moments_batch(_pad4(t), eps=0.0, saturation=None)        # {n, mean, sum d^2, ...}
+    return mom[:, 2] / mom[:, 0]
+
+
 def _std_scale(t, remove_mean: bool):
     """1/var per frame (population variance, corr.py:229-235); 1 where the variance is 0."""
-    var = t.double().var(dim=(1, 2), unbiased=False)
+    var = _frame_variances(t)
     one = var.new_ones(())
     return (one / var.where(var > 0, one)).float()
 
@@ -134,8 +144,8 @@ def xcorr2d(a, b, *, x=None, y=None, dx: float = 1.0, dy: float = 1.0, remove_me
     out = torch.empty((1, ny, nx), dtype=torch.float32, device=ta.device)
     _ffi.check(_ffi.lib().b4d_xcorr2d(pl.handle, D.ptr(ta), D.ptr(tb), 1, D.ptr(out), flags, _ffi.stream_ptr()))
     if standardize and normalize == "none":
-        sa = ta.double().std(unbiased=False)
-        sb = tb.double().std(unbiased=False)
+        sa = float(_frame_variances(ta)[0]) ** 0.5
+        sb = float(_frame_variances(tb)[0]) ** 0.5
         out *= float(1.0 / ((sa if sa > 0 else 1.0) * (sb if sb > 0 else 1.0)))
     corr = out[0]
     return (corr if return_tensors else D.to_host(corr, np.float64)), xlag, ylag

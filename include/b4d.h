@@ -161,7 +161,8 @@ int b4d_to_f32(const void* src, int dtype, size_t n, float* dst, void* stream);
 /* metrics/sharpness.py:752-861 eigenvalues (STA2): J = (x - mean(x)) / ||x||_2, eig_i = s_i(J)^2 / (M N - 1).
  * The reference takes every singular value from LAPACK and uses the first k (default 5); this returns the leading
  * nout (<= 8) of them, descending, from the Gram matrix of the smaller side (MFMA) and a 32-vector block subspace
- * iteration with float64 Cholesky-QR / Rayleigh-Ritz.  min(ny, nx) >= 64 required (B4D_ESIZE otherwise).
+ * iteration with float64 Cholesky-QR / Rayleigh-Ritz; frames with min(ny, nx) < 64 take every eigenvalue of the Gram
+ * matrix from a parallel cyclic Jacobi in float64.
  * frames: DEVICE (batch, ny, nx) float32.  out: HOST (batch, nout) float64; NaN rows for frames holding non-finite
  * pixels or no energy.  Synchronises the stream.                                                                  */
 int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int nx, double* out, int nout, void* stream);

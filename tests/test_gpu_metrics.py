@@ -179,7 +179,8 @@ def test_stack_stats_vs_reference_golden(gm, golden):
     np.testing.assert_allclose(got["tiles"]["stats"]["mean"]["mean"], ref["tiles"]["stats"]["mean"]["mean"], rtol=1e-10)
 
 
-@pytest.mark.parametrize("shape", [(1, 512, 512), (2, 300, 520), (2, 520, 300), (5, 228, 228), (1, 64, 64), (1, 1024, 2048)])
+@pytest.mark.parametrize("shape", [(1, 512, 512), (2, 300, 520), (2, 520, 300), (5, 228, 228), (1, 64, 64), (1, 1024, 2048),
+                                   (3, 40, 40), (2, 33, 200), (2, 150, 17), (1, 5, 7)])   # < 64 a side: float64 Jacobi path
 def test_sta2_eigenvalues_vs_oracle(gm, shape):
     """b4d_sta2_eigenvalues (Gram on MFMA + block subspace iteration) against the oracle's dense SVD
     (metrics/sharpness.py:752-861).  Tolerance 1e-5 relative on the k = 5 sum, e1, e2 (float32 Gram matrix)."""
@@ -197,6 +198,8 @@ def test_sta2_eigenvalues_vs_oracle(gm, shape):
         for key in ("eigenvalues", "e1", "e2"):
             assert got[i][key] == pytest.approx(want[key], rel=1e-5), (shape, i, key)
         assert got[i]["re"] == pytest.approx(want["re"], rel=2e-5)
+    with pytest.raises(NotImplementedError):
+        SH._eigenvalues_batch(torch.from_numpy(frames).cuda(), k=9)
     # low-rank image: rank 3 < subspace width, eigenvalues beyond the rank are ~0
     rng = np.random.default_rng(3)
     lr = (rng.random((h, 3)) @ rng.random((3, w))).astype(np.float32)
