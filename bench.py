@@ -99,6 +99,9 @@ def main():
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # modulo: lets a 1-GPU box rehearse N > 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node by contract: keep every rendezvous on the loopback interface (the container hostname may not resolve)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         # one process per GPU; RCCL ("nccl") carries device collectives (none on this data path: frames are
         # sharded, nothing is exchanged), gloo carries the host-side barrier and the max-over-ranks of the timing
         dist.init_process_group(backend="cpu:gloo,cuda:nccl")
