@@ -32,6 +32,14 @@ FRAMES_PER_GPU = 256
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def baseline_metric() -> str:
+    """BASELINE.json's own metric string (frames/s is `value`; the roofline share is in `roofline` / `pipeline_roofline`)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "frames/s (2048\u00d72048 fp32) through FFT\u2192PSD\u2192autocorr; % HBM roofline"
+
+
 def algorithmic_bytes(n: int):
     """Per-frame byte model.  pipe = SURVEY.md §8(d) 4-pass figure (12 N^2 + 40 N Nh);
     col = what the fused column kernel must move: half spectrum in (8 N N/2) + PSD out (4 N^2) + rows 0..N/2+1 of the
@@ -161,7 +169,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "frames/s (2048x2048 fp32) through FFT->PSD->autocorr",
+            "metric": baseline_metric(),
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
