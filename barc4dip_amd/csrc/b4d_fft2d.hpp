@@ -651,6 +651,7 @@ int general_dft2(const b4d_plan* pl, const void* X, bool x_real, int batch, int 
 // b4d_wiener.hip: general-length 1-D engine (n = P * A * B, in-LDS mixed radix) and batched complex transpose
 namespace b4d {
 bool pm_fusable(int n);
+bool pm_supported(int n);   // fused split, or Bluestein over a power-of-two fused transform (n <= 4096)
 int pm_rows(const void* in, bool real_in, float2* out, int S, int n, const float2* tw, bool inverse, float scale, hipStream_t st);
 int transpose_batch(const float2* in, float2* out, int rows, int cols, int batch, hipStream_t st);
 }  // namespace b4d

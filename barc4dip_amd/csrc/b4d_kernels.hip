@@ -14,7 +14,7 @@ extern "C" {
 const char* b4d_version(void) { return "b4d 0.1.0 (gfx950)"; }
 const char* b4d_last_error(void) { return last_error().c_str(); }
 static bool large_ok(int ny, int nx) {
-    return ny >= 2 && nx >= 2 && ny <= 8192 && nx <= 8192 && (size_t)ny * nx <= ((size_t)1 << 26) && pm_fusable(ny) && pm_fusable(nx);
+    return ny >= 2 && nx >= 2 && ny <= 8192 && nx <= 8192 && (size_t)ny * nx <= ((size_t)1 << 26) && pm_supported(ny) && pm_supported(nx);
 }
 int b4d_size_supported(int ny, int nx) {
     return (pow2_ok(ny) && pow2_ok(nx)) || (general_ok(ny) && general_ok(nx)) || large_ok(ny, nx);

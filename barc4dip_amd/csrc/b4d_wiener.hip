@@ -92,6 +92,7 @@ struct FusedIO {
     const float* amax;    // max|frame| (device scalar)
     int h, w, py, px, clip;
     int half, rows;       // pair modes: half-row length N/2 + 1 and the number of (padded) rows
+    int filt_bcast;       // the pointwise multiplier is ONE row shared by every sequence (Bluestein's chirp spectrum)
 };
 
 template <int P, int IN, int OUT, bool ONEBUF>
@@ -418,7 +419,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
     }
     for (int k = threadIdx.x; k < N; k += FT) {
         float2 v = buf0[k];
-        if (filt) v = cmulf(v, filt[s * (size_t)N + k]);
+        if (filt) v = cmulf(v, filt[(io.filt_bcast ? 0 : s * (size_t)N) + k]);
         if (conj_io) v.y = -v.y;
         out[s * (size_t)N + k] = make_float2(v.x * scale, v.y * scale);
     }
@@ -717,12 +718,135 @@ bool pm_fusable(int n) {
     split_ab(P, M, &A, &B);
     return A > 0;
 }
+
+// ---- Bluestein (chirp-z) for lengths without a small-factor split (e.g. 2056 = 8 * 257): with c[n] = exp(-i pi n^2 / N),
+//   X[k] = c[k] * sum_n (x[n] c[n]) conj(c[k - n]),
+// a convolution carried by two fused power-of-two transforms of length L >= 2 N - 1 and a pointwise product with the
+// precomputed spectrum of the chirp.  Per-length tables are cached for the life of the process.
+__global__ void __launch_bounds__(256) k_blue_pre(const void* __restrict__ xin, int real_in, int conj_in, int N, int L,
+                                                  const float2* __restrict__ chirp, float2* __restrict__ a) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= L) return;
+    const size_t s = blockIdx.y;
+    float2 v = make_float2(0.f, 0.f);
+    if (n < N) {
+        float2 x;
+        if (real_in) {
+            x = make_float2(static_cast<const float*>(xin)[s * N + n], 0.f);
+        } else {
+            x = static_cast<const float2*>(xin)[s * N + n];
+            if (conj_in) x.y = -x.y;
+        }
+        v = cmulf(x, chirp[n]);
+    }
+    a[s * (size_t)L + n] = v;
+}
+
+__global__ void __launch_bounds__(256) k_blue_post(const float2* __restrict__ c, int N, int L, const float2* __restrict__ chirp,
+                                                   int conj_out, float scale, float2* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const size_t s = blockIdx.y;
+    float2 v = cmulf(c[s * (size_t)L + k], chirp[k]);
+    if (conj_out) v.y = -v.y;
+    out[s * (size_t)N + k] = make_float2(v.x * scale, v.y * scale);
+}
+
+namespace {
+struct BluePlan {
+    int n = 0, L = 0;
+    float2* chirp = nullptr;   // c[n] = exp(-i pi n^2 / N), n < N
+    float2* bspec = nullptr;   // FFT_L of b[m] = conj(c[|m|]) wrapped to length L
+    float2* twL = nullptr;     // L-point twiddles
+};
+std::mutex g_blue_mu;
+std::vector<BluePlan> g_blue_plans;
+void* g_blue_ws = nullptr;
+size_t g_blue_ws_bytes = 0;
+
+int blue_len(int n) {
+    int L = 64;
+    while (L < 2 * n - 1) L *= 2;
+    return L;
+}
+
+int blue_plan(int n, hipStream_t st, BluePlan* out) {
+    for (const BluePlan& p : g_blue_plans)
+        if (p.n == n) {
+            *out = p;
+            return B4D_OK;
+        }
+    BluePlan p;
+    p.n = n;
+    p.L = blue_len(n);
+    std::vector<float2> c(n), b(p.L, make_float2(0.f, 0.f));
+    for (int k = 0; k < n; ++k) {
+        const long long q = ((long long)k * k) % (2LL * n);        // k^2 mod 2N keeps the phase exact
+        const double a = -M_PI * (double)q / (double)n;
+        c[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        const float2 bk = make_float2(c[k].x, -c[k].y);
+        b[k] = bk;
+        if (k) b[p.L - k] = bk;
+    }
+    int rc = make_twiddles(p.L, &p.twL);
+    if (rc) return rc;
+    B4D_HIP(hipMalloc((void**)&p.chirp, sizeof(float2) * n));
+    B4D_HIP(hipMalloc((void**)&p.bspec, sizeof(float2) * p.L));
+    B4D_HIP(hipMemcpy(p.chirp, c.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    B4D_HIP(hipMemcpy(p.bspec, b.data(), sizeof(float2) * p.L, hipMemcpyHostToDevice));
+    int P, M, A, B;
+    split_pm(p.L, &P, &M);
+    split_ab(P, M, &A, &B);
+    if (A <= 0) return fail(B4D_ESIZE, "Bluestein length has no fused split");
+    if ((rc = dft_rows(p.bspec, false, nullptr, nullptr, p.bspec, 1, P, M, p.twL, nullptr, false, nullptr, 1.f, st, A, B))) return rc;
+    B4D_HIP(hipStreamSynchronize(st));
+    g_blue_plans.push_back(p);
+    *out = p;
+    return B4D_OK;
+}
+
+int blue_rows(const void* in, bool real_in, float2* out, int S, int n, bool inverse, float scale, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_blue_mu);
+    BluePlan bp;
+    int rc = blue_plan(n, st, &bp);
+    if (rc) return rc;
+    const size_t need = sizeof(float2) * (size_t)S * bp.L;
+    if (need > g_blue_ws_bytes) {
+        if (g_blue_ws) (void)hipFree(g_blue_ws);
+        g_blue_ws = nullptr;
+        g_blue_ws_bytes = 0;
+        hipError_t e = hipMalloc(&g_blue_ws, need);
+        if (e != hipSuccess) return fail(B4D_ENOMEM, std::string("Bluestein workspace: ") + hipGetErrorString(e));
+        g_blue_ws_bytes = need;
+    }
+    float2* a = static_cast<float2*>(g_blue_ws);
+    int P, M, A, B;
+    split_pm(bp.L, &P, &M);
+    split_ab(P, M, &A, &B);
+    hipLaunchKernelGGL(k_blue_pre, dim3((bp.L + 255) / 256, S), dim3(256), 0, st, in, real_in ? 1 : 0, inverse ? 1 : 0, n, bp.L, bp.chirp, a);
+    B4D_HIP(hipGetLastError());
+    FusedIO io{};
+    io.filt_bcast = 1;
+    if ((rc = dft_rows(a, false, nullptr, nullptr, a, S, P, M, bp.twL, nullptr, false, bp.bspec, 1.f, st, A, B, &io))) return rc;
+    if ((rc = dft_rows(a, false, nullptr, nullptr, a, S, P, M, bp.twL, nullptr, true, nullptr, 1.0f / (float)bp.L, st, A, B))) return rc;
+    hipLaunchKernelGGL(k_blue_post, dim3((n + 255) / 256, S), dim3(256), 0, st, a, n, bp.L, bp.chirp, inverse ? 1 : 0, scale, out);
+    B4D_HIP(hipGetLastError());
+    B4D_HIP(hipStreamSynchronize(st));   // the shared workspace is reused by the next call
+    return B4D_OK;
+}
+}  // namespace
+
+bool pm_supported(int n) { return n >= 2 && (pm_fusable(n) || n <= 4096); }
+
 // S contiguous sequences of length n: out = DFT(in), or conj(DFT(conj(in))) * scale when inverse; tw: n-point twiddles
 int pm_rows(const void* in, bool real_in, float2* out, int S, int n, const float2* tw, bool inverse, float scale, hipStream_t st) {
     int P, M, A, B;
     split_pm(n, &P, &M);
     split_ab(P, M, &A, &B);
-    if (A <= 0) return fail(B4D_ESIZE, "length " + std::to_string(n) + " has no P * A * B split that fits the fused transform");
+    if (A <= 0) {
+        if (n <= 4096) return blue_rows(in, real_in, out, S, n, inverse, scale, st);
+        return fail(B4D_ESIZE, "length " + std::to_string(n) + " has no P * A * B split that fits the fused transform");
+    }
     return dft_rows(in, real_in, nullptr, nullptr, out, S, P, M, tw, nullptr, inverse, nullptr, scale, st, A, B);
 }
 int transpose_batch(const float2* in, float2* out, int rows, int cols, int batch, hipStream_t st) {

@@ -9,8 +9,8 @@ Differences (documented in DESIGN.md):
     outputs are cast back up so that dtypes match what the reference returns);
   * inputs may be ROCm torch tensors; ``return_tensors=True`` keeps results on the device;
   * 2-D transforms: power-of-two ny, nx in [64, 4096] (FFT kernels), any ny, nx <= 512 (DFT-matrix products) or sides
-    up to 8192 that split as 2^k * A * B with A + B <= 128, e.g. 2560 x 2160 (fused mixed-radix transform);
-    ``NotImplementedError`` otherwise;
+    up to 8192 that split as 2^k * A * B with A + B <= 128, e.g. 2560 x 2160 (fused mixed-radix transform), any other
+    side up to 4096 through Bluestein's chirp-z; ``NotImplementedError`` otherwise;
   * stacks (T, ny, nx) are accepted by the ``*_stack`` functions (batched launches).
 1-D helpers and axes are host-side NumPy (negligible cost).
 """

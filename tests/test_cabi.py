@@ -42,7 +42,8 @@ def test_no_gpu_calls_needed_for_introspection(lib):
     assert lib.b4d_size_supported(64, 4096) == 1
     assert lib.b4d_size_supported(171, 170) == 1                       # DFT-matrix range (any side <= 512)
     assert lib.b4d_size_supported(2160, 2560) == 1 and lib.b4d_size_supported(100, 2048) == 1   # 2^k * A * B splits
-    assert lib.b4d_size_supported(1042, 2048) == 0                     # 1042 = 2 * 521
+    assert lib.b4d_size_supported(1042, 2048) == 1                     # 1042 = 2 * 521: Bluestein
+    assert lib.b4d_size_supported(4099, 2048) == 0                     # prime beyond the Bluestein range
     assert lib.b4d_size_supported(9000, 64) == 0 and lib.b4d_size_supported(1, 64) == 0
     assert lib.b4d_plan_destroy(None) == 0
 

@@ -228,7 +228,8 @@ def test_stack_stats_default_tracker_any_size(gm):
     np.testing.assert_allclose(got["temporal"]["abs"]["dx"], sh[:, 1], atol=0.25)
 
 
-@pytest.mark.parametrize("case", ["u16_384", "f64_300x420", "noncontig", "fortran", "int32_130", "withnan_512", "const_256", "zeros_256"])
+@pytest.mark.parametrize("case", ["u16_384", "f64_300x420", "noncontig", "fortran", "int32_130", "withnan_512", "const_256", "zeros_256",
+                                  "prime_1042x771"])
 def test_awkward_inputs_match_oracle(gm, case):
     """dtypes, strides, odd sizes, NaNs, constant frames: same values, same exception types and same result dtypes as the
     oracle (NumPy promotes everything but float16/float32 to double precision; a constant frame's autocorrelation is 0)."""
@@ -247,6 +248,7 @@ def test_awkward_inputs_match_oracle(gm, case):
         "withnan_512": lambda: np.where(rng.random((512, 512)) < 1e-4, np.nan, base[:512, :512]).astype(np.float32),
         "const_256": lambda: np.full((256, 256), 7.0, np.float32),
         "zeros_256": lambda: np.zeros((256, 256), np.float32),
+        "prime_1042x771": lambda: synth.speckle_frame(1100, 8)[:1042, :771].copy(),     # 1042 = 2 * 521, 771 = 3 * 257: Bluestein sides
     }[case]()
 
     def both(f, g):

@@ -112,9 +112,9 @@ def test_errors(gs):
     with pytest.raises(ValueError):
         gs.autocorr2d(np.zeros((4, 512, 512), dtype=np.float32))
     with pytest.raises(NotImplementedError):           # no CPU fallback for sizes without a plan
-        gs.psd2d(np.zeros((1042, 1042), dtype=np.float32))             # 1042 = 2 * 521: no small-factor split
+        gs.psd2d(np.zeros((4099, 64), dtype=np.float32))               # prime side beyond the Bluestein range (4096)
     with pytest.raises(NotImplementedError):
-        gs.autocorr2d(np.zeros((1042, 2048), dtype=np.float32))
+        gs.autocorr2d(np.zeros((64, 9000), dtype=np.float32))
     with pytest.raises(NotImplementedError):
         gs.psd2d(np.zeros((512, 512), dtype=np.complex64))             # PSD / correlations take real frames only
 
@@ -315,3 +315,20 @@ def test_fused_transform_factorisations(gs, shape):
     assert nerr(gs.fft2d(img)[0], S.fft2d(r64)[0]) < TOL
     ac = gs.autocorr2d(img)[0]
     assert nerr(ac, S.autocorr2d(r64)[0]) < TOL and ac[shape[0] // 2, shape[1] // 2] == 1.0
+
+
+@pytest.mark.parametrize("shape", [(1042, 1042), (2056, 2464), (1031, 520), (600, 4093)])
+def test_bluestein_lengths_vs_oracle(gs, shape):
+    """Sides with a large prime factor (1042 = 2 * 521, 2056 = 8 * 257, 1031 and 4093 prime) have no small-factor
+    split: chirp-z over two fused power-of-two transforms.  Same 1e-5 bar."""
+    from oracle import signal_np as S
+
+    rng = np.random.default_rng(shape[0] + 3 * shape[1])
+    img = (rng.poisson(300.0, size=shape) + rng.random(shape)).astype(np.float32)
+    r64 = img.astype(np.float64)
+    assert nerr(gs.fft2d(img)[0], S.fft2d(r64)[0]) < TOL
+    assert nerr(gs.psd2d(img)[0], S.psd2d(r64)[0]) < TOL
+    ac = gs.autocorr2d(img)[0]
+    assert nerr(ac, S.autocorr2d(r64)[0]) < TOL and ac[shape[0] // 2, shape[1] // 2] == 1.0
+    z = (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(np.complex64)
+    assert nerr(gs.fft.ifft2d(gs.fft2d(z)[0]), z) < TOL
