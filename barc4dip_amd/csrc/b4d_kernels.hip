@@ -36,8 +36,8 @@ static int plan_create_impl(int ny, int nx, int chunk, bool force_general, b4d_p
     *out = nullptr;
     if (!b4d_size_supported(ny, nx))
         return fail(B4D_ESIZE, "plans need power-of-two ny, nx in [64, 4096] (FFT kernels), any ny, nx in [2, 512] "
-                               "(DFT-matrix path) or sides up to 8192 that split as 2^k * A * B with A + B <= 128 (fused "
-                               "mixed-radix path); got " + std::to_string(ny) + "x" + std::to_string(nx));
+                               "(DFT-matrix path), sides up to 8192 that split as 2^k * A * B with A + B <= 128 (fused "
+                               "mixed-radix path) or any other side up to 4096 (Bluestein); got " + std::to_string(ny) + "x" + std::to_string(nx));
     if (chunk < 1) return fail(B4D_EINVAL, "chunk must be >= 1");
     b4d_plan* p = new b4d_plan();
     p->ny = ny;

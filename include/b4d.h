@@ -42,13 +42,15 @@ typedef struct b4d_plan b4d_plan;
 /* Library / device ------------------------------------------------------------------- */
 const char* b4d_version(void);
 const char* b4d_last_error(void);
-/* 1 if (ny, nx) has a native plan: ny, nx powers of two in [64, 4096]. */
+/* 1 if (ny, nx) has a plan: powers of two in [64, 4096] (radix FFT kernels); any sides <= 512 (DFT-matrix products);
+ * sides <= 8192 that split as 2^k * A * B with A + B <= 128 (fused in-LDS mixed radix) or any other side <= 4096
+ * (Bluestein over that transform), at most 2^26 pixels. */
 int b4d_size_supported(int ny, int nx);
 
 /* Plans ------------------------------------------------------------------------------
  * A plan owns the twiddle tables and a workspace of `chunk` half-spectra
- * (chunk * ny * nx/2 complex64).  Batches larger than `chunk` are processed chunk by
- * chunk so that intermediates stay in the 256 MiB Infinity Cache.                      */
+ * (chunk * ny * nx/2 complex64; general-length plans: three full complex buffers).  Batches larger
+ * than `chunk` are processed chunk by chunk.                                            */
 int b4d_plan_create(int ny, int nx, int chunk, b4d_plan** out);
 int b4d_plan_destroy(b4d_plan* plan);
 size_t b4d_plan_workspace_bytes(const b4d_plan* plan);
