@@ -654,6 +654,9 @@ bool pm_fusable(int n);
 bool pm_supported(int n);   // fused split, or Bluestein over a power-of-two fused transform (n <= 4096)
 int pm_rows(const void* in, bool real_in, float2* out, int S, int n, const float2* tw, bool inverse, float scale, hipStream_t st);
 int transpose_batch(const float2* in, float2* out, int rows, int cols, int batch, hipStream_t st);
+int pm_rows_pair_fwd(const float* in, float2* half_out, int frames, int rows, int n, const float2* tw, hipStream_t st);
+int pm_rows_pair_inv(const float2* half_in, float* real_out, int frames, int rows, int n, const float2* tw, float scale, const float* peak,
+                     hipStream_t st);
 }  // namespace b4d
 // b4d_track.hip: x[b] /= max|x[b]| for `batch` maps of n floats; scratch holds >= 256 * batch floats
 int normalise_by_absmax(float* x, size_t n, int batch, float* scratch, hipStream_t st);

@@ -209,6 +209,56 @@ __global__ void __launch_bounds__(256) k_gen_real_out(const float2* __restrict__
     out[fo + (size_t)((y + ny / 2) % ny) * nx + (x + nx / 2) % nx] = v;
 }
 
+// ---- half-spectrum path of the fused mixed-radix plans (real rows ride in pairs, only nx/2 + 1 columns are transformed)
+// Power spectrum from the TRANSPOSED half spectrum F_T (batch, Wh, ny): P_T (real, same layout; DC zeroed for mean
+// removal) for the inverse transform, and the full fftshift-ed PSD (direct half + Hermitian mirror) through a 32 x 32 LDS
+// transpose so that both sides are coalesced.  grid (ceil(ny/32), ceil(Wh/32), batch), block (32, 8)
+__global__ void __launch_bounds__(256) k_half_power(const float2* __restrict__ FT, int ny, int nx, float* __restrict__ PT,
+                                                    float* __restrict__ psd, float psd_scale, unsigned flags) {
+    __shared__ float t[32][33];
+    const int Wh = nx / 2 + 1;
+    const int ky0 = blockIdx.x * 32, kx0 = blockIdx.y * 32;
+    const size_t fh = (size_t)blockIdx.z * Wh * ny, ff = (size_t)blockIdx.z * ny * nx;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int kx = kx0 + i, ky = ky0 + threadIdx.x;
+        float p = 0.f;
+        if (kx < Wh && ky < ny) {
+            const float2 f = FT[fh + (size_t)kx * ny + ky];
+            p = f.x * f.x + f.y * f.y;
+            if (PT) PT[fh + (size_t)kx * ny + ky] = (kx == 0 && ky == 0 && (flags & B4D_REMOVE_MEAN)) ? 0.f : p;
+        }
+        t[i][threadIdx.x] = p;
+    }
+    if (!psd) return;
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int ky = ky0 + i, kx = kx0 + threadIdx.x;
+        if (ky >= ny || kx >= Wh) continue;
+        const float v = t[threadIdx.x][i] * psd_scale;
+        psd[ff + (size_t)((ky + ny / 2) % ny) * nx + (kx + nx / 2) % nx] = v;
+        if (kx > 0 && 2 * kx != nx)   // Hermitian mirror (-ky, -kx); the Nyquist column of an even nx is its own mirror
+            psd[ff + (size_t)(((ny - ky) % ny + ny / 2) % ny) * nx + ((nx - kx) + nx / 2) % nx] = v;
+    }
+}
+
+// unscaled zero-lag value of every frame from the column-inverted half spectrum G_T (batch, Wh, ny):
+// sum over the full kx range of G[kx][y = 0] = G[0] + 2 sum Re G[kx] (+ G[nx/2] for even nx).  grid (batch), block 256
+__global__ void __launch_bounds__(256) k_half_peak(const float2* __restrict__ GT, int ny, int nx, float* __restrict__ peak) {
+    __shared__ double sh[4];
+    const int Wh = nx / 2 + 1;
+    const float2* g = GT + (size_t)blockIdx.x * Wh * ny;
+    double acc = 0.0;
+    for (int kx = threadIdx.x; kx < Wh; kx += 256) {
+        const double v = (double)g[(size_t)kx * ny].x;
+        acc += (kx == 0 || 2 * kx == nx) ? v : 2.0 * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) peak[blockIdx.x] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
 }  // namespace b4d
 
 using namespace b4d;
@@ -272,6 +322,32 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
                          unsigned flags, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
     const dim3 eg((npix + 255) / 256, 1);
+    if (pl->large && pm_fusable(nx) && pm_fusable(ny)) {
+        // half-spectrum path: pair rows -> transpose -> columns on nx/2 + 1 sequences -> |F|^2 (+ PSD) -> inverse columns ->
+        // transpose -> Hermitian pair rows written fftshift-ed and normalised: ~56 instead of ~148 bytes per pixel
+        const int Wh = nx / 2 + 1;
+        for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
+            const int nb = std::min(pl->chunk, batch - b0);
+            const size_t off = (size_t)b0 * npix;
+            int rc = pm_rows_pair_fwd(frames + off, pl->gbuf1, nb, ny, nx, pl->tw_x, st);
+            if (rc == B4D_OK) rc = transpose_batch(pl->gbuf1, pl->gbuf2, ny, Wh, nb, st);
+            if (rc == B4D_OK) rc = pm_rows(pl->gbuf2, false, pl->gbuf2, nb * Wh, ny, pl->tw_y, false, 1.f, st);
+            if (rc) return rc;
+            float* PT = reinterpret_cast<float*>(pl->gbuf1);
+            hipLaunchKernelGGL(k_half_power, dim3((ny + 31) / 32, (Wh + 31) / 32, nb), dim3(32, 8), 0, st, pl->gbuf2, ny, nx,
+                               autocorr ? PT : nullptr, psd ? psd + off : nullptr, psd_scale, flags);
+            B4D_HIP(hipGetLastError());
+            if (!autocorr) continue;
+            if ((rc = pm_rows(PT, true, pl->gbuf2, nb * Wh, ny, pl->tw_y, true, 1.f, st))) return rc;
+            float* peak = reinterpret_cast<float*>(pl->gbuf3);
+            const bool norm = (flags & B4D_NORM_PEAK) != 0;
+            if (norm) hipLaunchKernelGGL(k_half_peak, dim3(nb), dim3(256), 0, st, pl->gbuf2, ny, nx, peak);
+            if ((rc = transpose_batch(pl->gbuf2, pl->gbuf1, Wh, ny, nb, st))) return rc;
+            if ((rc = pm_rows_pair_inv(pl->gbuf1, autocorr + off, nb, ny, nx, pl->tw_x, 1.0f / ((float)nx * (float)ny), norm ? peak : nullptr, st)))
+                return rc;
+        }
+        return B4D_OK;
+    }
     for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
         const int nb = std::min(pl->chunk, batch - b0);
         const size_t off = (size_t)b0 * npix;

@@ -61,9 +61,13 @@ __global__ void __launch_bounds__(256) k_pm_pre(const void* __restrict__ xin, fl
 //       (h, w) frame (np.pad(..., "reflect") / max|frame|, filters.py:252-261: no padded copy in memory)
 //       3 as 2 for the row PAIR (2 s, 2 s + 1) packed as real + i imaginary part of one transform
 //       4 the Hermitian pair: half rows 2 s, 2 s + 1 (io.half values each) extended to Ga + i Gb (inverse pass)
+//       5 two plain real rows of a (frames, io.rows, N) float stack packed as real + i imaginary part
 //   OUT 0 complex rows | 1 clip(Re, -1, 1) * max|frame| cropped back to (h, w) (filters.py:266, 287-289)
 //       2 the pair's half spectra Fa, Fb (k = 0 .. io.half - 1) unpacked to half rows 2 s, 2 s + 1
 //       3 as 1 for the pair: real part -> row 2 s, imaginary part -> row 2 s + 1
+//       4 the pair's two real rows written fftshift-ed into a (frames, io.rows, N) float stack, scaled or divided by
+//         the frame's zero-lag value io.amax[frame] (autocorrelation peak normalisation)
+//   Pair modes index sequences as s = frame * ceil(io.rows / 2) + pair: pairs never straddle two frames.
 // grid (S), block FT, dynamic LDS (2 N + A + B) complex values.
 constexpr int FT_MAX = 1024, FT_ONEBUF = 512;
 // acc += x * w (complex) in two packed FMAs
@@ -93,6 +97,7 @@ struct FusedIO {
     int h, w, py, px, clip;
     int half, rows;       // pair modes: half-row length N/2 + 1 and the number of (padded) rows
     int filt_bcast;       // the pointwise multiplier is ONE row shared by every sequence (Bluestein's chirp spectrum)
+    int norm_peak;        // OUT 4: divide by io.amax[frame] when it is > 0 and force the zero lag to exactly 1
 };
 
 template <int P, int IN, int OUT, bool ONEBUF>
@@ -130,6 +135,11 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
         fsc = io.amax[0];
         fok = isfinite(fsc) && fsc != 0.f;
     }
+    // pair modes: sequence s = frame * hp + pr covers rows 2 pr, 2 pr + 1 of that frame
+    const int hp = (io.rows + 1) / 2 > 0 ? (io.rows + 1) / 2 : 1;
+    const int pfr = (int)(s / hp), ppr = (int)(s % hp);
+    const size_t prow0 = (size_t)pfr * io.rows + 2 * ppr;     // global index of the pair's first row
+    const bool phas_b = 2 * ppr + 1 < io.rows;
     // ---- radix-P butterflies over n1 (stride M) and the twiddle W_N^{n2 k1}
     for (int n2 = threadIdx.x; n2 < M; n2 += FT) {
         float2 v[P];
@@ -148,11 +158,15 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
                     q[e] = (fok && row < io.rows) ? io.frame[(size_t)y * io.w + x] / fsc : 0.f;
                 }
                 v[n1] = make_float2(q[0], q[1]);
+            } else if (IN == 5) {
+                const int idx = M * n1 + n2;
+                const float* pa = static_cast<const float*>(xin) + prow0 * N;
+                v[n1] = make_float2(pa[idx], phas_b ? pa[N + idx] : 0.f);
             } else if (IN == 4) {
                 const int idx = M * n1 + n2, j = idx <= N / 2 ? idx : N - idx;
-                const float2* pa = static_cast<const float2*>(xin) + (size_t)(2 * s) * io.half;
+                const float2* pa = static_cast<const float2*>(xin) + prow0 * io.half;
                 const float2 fa = pa[j];
-                const float2 fb = (2 * (int)s + 1 < io.rows) ? pa[io.half + j] : make_float2(0.f, 0.f);
+                const float2 fb = phas_b ? pa[io.half + j] : make_float2(0.f, 0.f);
                 // Ga + i Gb, Hermitian-extended beyond N/2; then the inverse's input conjugation
                 const float2 z = idx <= N / 2 ? make_float2(fa.x - fb.y, fa.y + fb.x) : make_float2(fa.x + fb.y, fb.x - fa.y);
                 v[n1] = make_float2(z.x, -z.y);
@@ -383,9 +397,28 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
         }
     __syncthreads();
 #endif
+    if (OUT == 4) {
+        const float pk = io.norm_peak ? io.amax[pfr] : 0.f;
+        const bool unit = io.norm_peak && pk > 0.f;
+        const float se = unit ? 1.0f / pk : scale;
+        float* fo = io.crop + (size_t)pfr * io.rows * N;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int y = 2 * ppr + e;
+            if (y >= io.rows) continue;
+            float* orow = fo + (size_t)((y + io.rows / 2) % io.rows) * N;
+            for (int x = threadIdx.x; x < N; x += FT) {
+                const float2 z = buf0[x];
+                float v = (e == 0 ? z.x : -z.y) * se;     // conj(buf0): real part row a, imaginary part row b
+                if (unit && y == 0 && x == 0) v = 1.0f;
+                orow[(x + N / 2) % N] = v;
+            }
+        }
+        return;
+    }
     if (OUT == 2) {
-        float2* oa = out + (size_t)(2 * s) * io.half;
-        const bool has_b = 2 * (int)s + 1 < io.rows;
+        float2* oa = out + prow0 * io.half;
+        const bool has_b = phas_b;
         for (int k = threadIdx.x; k < io.half; k += FT) {
             const float2 z = buf0[k], w = buf0[k == 0 ? 0 : N - k];
             oa[k] = make_float2(0.5f * (z.x + w.x), 0.5f * (z.y - w.y));
@@ -651,6 +684,8 @@ template <int P>
 static int pm_fused_launch(const void* x, int in_mode, int out_mode, float2* out, const float2* tw, int A, int B, int S, const float2* filt,
                            int conj_io, float scale, const FusedIO& io, hipStream_t st) {
     if (in_mode == 3) return pm_fused_launch2<P, 3, 2>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
+    if (in_mode == 5) return pm_fused_launch2<P, 5, 2>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
+    if (in_mode == 4 && out_mode == 4) return pm_fused_launch2<P, 4, 4>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
     if (in_mode == 4) return pm_fused_launch2<P, 4, 3>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
     if (out_mode == 1) return pm_fused_launch2<P, 0, 1>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
     if (in_mode == 2) return pm_fused_launch2<P, 2, 0>(x, out, tw, A, B, S, filt, conj_io, scale, io, st);
@@ -848,6 +883,34 @@ int pm_rows(const void* in, bool real_in, float2* out, int S, int n, const float
         return fail(B4D_ESIZE, "length " + std::to_string(n) + " has no P * A * B split that fits the fused transform");
     }
     return dft_rows(in, real_in, nullptr, nullptr, out, S, P, M, tw, nullptr, inverse, nullptr, scale, st, A, B);
+}
+// Real rows in pairs (SURVEY's R2C / C2R passes for general lengths; n must have a fused split):
+//   forward: (frames, rows, n) float -> (frames, rows, n/2 + 1) half spectra
+//   inverse: half rows -> (frames, rows, n) float, fftshift-ed in both axes, scaled by `scale` or, with `peak`
+//            (device, one unscaled zero-lag value per frame), divided by it with the zero lag forced to 1
+int pm_rows_pair_fwd(const float* in, float2* half_out, int frames, int rows, int n, const float2* tw, hipStream_t st) {
+    int P, M, A, B;
+    split_pm(n, &P, &M);
+    split_ab(P, M, &A, &B);
+    if (A <= 0) return fail(B4D_ESIZE, "pair transform needs a fused split");
+    FusedIO io{};
+    io.half = n / 2 + 1;
+    io.rows = rows;
+    return dft_rows(in, true, nullptr, nullptr, half_out, frames * ((rows + 1) / 2), P, M, tw, nullptr, false, nullptr, 1.f, st, A, B, &io, 5, 0);
+}
+int pm_rows_pair_inv(const float2* half_in, float* real_out, int frames, int rows, int n, const float2* tw, float scale, const float* peak,
+                     hipStream_t st) {
+    int P, M, A, B;
+    split_pm(n, &P, &M);
+    split_ab(P, M, &A, &B);
+    if (A <= 0) return fail(B4D_ESIZE, "pair transform needs a fused split");
+    FusedIO io{};
+    io.half = n / 2 + 1;
+    io.rows = rows;
+    io.crop = real_out;
+    io.amax = peak;
+    io.norm_peak = peak ? 1 : 0;
+    return dft_rows(half_in, false, nullptr, nullptr, nullptr, frames * ((rows + 1) / 2), P, M, tw, nullptr, true, nullptr, scale, st, A, B, &io, 4, 4);
 }
 int transpose_batch(const float2* in, float2* out, int rows, int cols, int batch, hipStream_t st) {
     return transpose_c(in, out, rows, cols, st, batch);
