@@ -84,6 +84,10 @@ def load_library(path: str | None = None):
             raise B4DUnavailable(
                 f"{p} not found: the HIP extension is not built (run __graft_entry__.build()). "
                 "barc4dip_amd has no CPU fallback.")
+        try:    # load PyTorch's HIP runtime first: libb4d.so must bind to the SAME libamdhip64 instance (a second copy of the
+            import torch  # noqa: F401    # runtime, loaded by dlopen-ing us before torch, does not see the devices)
+        except Exception:  # pragma: no cover - torch-less host tools still get the symbol table
+            pass
         lib = C.CDLL(p)
         missing = []
         for name, (res, args) in SIGNATURES.items():

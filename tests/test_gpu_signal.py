@@ -4,6 +4,8 @@ Tolerances (stated per SURVEY.md §8d): FFT/PSD/autocorrelation values are float
 and are compared NORMWISE with the float64 oracle: max|got-ref| <= 1e-5 * max|ref|.  Index
 outputs (arg-max of the autocorrelation) are exact, and the peak value is exactly 1.0.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -332,3 +334,17 @@ def test_bluestein_lengths_vs_oracle(gs, shape):
     assert nerr(ac, S.autocorr2d(r64)[0]) < TOL and ac[shape[0] // 2, shape[1] // 2] == 1.0
     z = (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(np.complex64)
     assert nerr(gs.fft.ifft2d(gs.fft2d(z)[0]), z) < TOL
+
+
+def test_library_loaded_before_torch_still_sees_the_gpu():
+    """Touching the C ABI (introspection) before anything imported torch must not strand libb4d.so on a second,
+    device-less copy of the HIP runtime (_ffi.load_library pulls torch's runtime in first)."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, '.'); from barc4dip_amd import _ffi; assert _ffi.supported(64, 64); "
+            "import numpy as np; from barc4dip_amd import signal as s; "
+            "p = s.psd2d(np.arange(4096, dtype=np.float32).reshape(64, 64))[0]; print(p.shape, float(p.max()) > 0)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "(64, 64) True" in out.stdout, out.stderr[-500:]
