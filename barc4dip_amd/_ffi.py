@@ -156,6 +156,7 @@ class Plan:
 
 
 _plans: dict = {}
+_MAX_CACHED_PLANS = 12
 _plans_lock = threading.Lock()
 
 
@@ -186,10 +187,12 @@ def get_plan(ny: int, nx: int, chunk: int | None = None, general: bool = False) 
     key = (int(ny), int(nx), int(chunk or default_chunk(ny, nx)), torch.cuda.current_device(),
            int(torch.cuda.current_stream().cuda_stream), bool(general))
     with _plans_lock:
-        pl = _plans.get(key)
+        pl = _plans.pop(key, None)
         if pl is None:
             pl = Plan(key[0], key[1], key[2], general=general)
-            _plans[key] = pl
+        _plans[key] = pl                       # most recently used last
+        while len(_plans) > _MAX_CACHED_PLANS:  # plans own up to 1 GiB of workspace each: keep a bounded LRU set
+            _plans.pop(next(iter(_plans)))     # dropped from the cache only; the plan dies with its last user
         return pl
 
 
