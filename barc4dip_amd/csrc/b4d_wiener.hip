@@ -77,6 +77,41 @@ __device__ __forceinline__ v2f cmac(v2f acc, v2f x, v2f w) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(x), "v"(w), "v"(t));
     return r;
 }
+// Dense small DFT on the matrix cores (the one dense contraction of this path; v_mfma_f32_16x16x4_f32 is exact f32 at
+// the packed-FP32 flop rate, but one ds_read_b64 per operand feeds 4 MFMAs = 1024 complex MACs: ~12 x less LDS traffic
+// than the 4 x 2 register blocks below).  Y(r, n) = sum_{k < R} T[k][r] * X(k, n) for r < R <= 32: one wave per strip
+// of 16 columns n, two 16 x 16 complex tiles (rows 0..15, 16..31), k in steps of 4.
+// Fragment maps (MI355X guide): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D: col = l & 15, row = 4 (l >> 4) + reg.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct DftTiles {
+    f32x4 r0, i0, r1, i1;
+};
+// tab: T[k * Tp + r]; x: this lane's column (nullptr = padding column), element k at x[k * xstride]
+__device__ __forceinline__ DftTiles small_dft_mfma(const float2* __restrict__ tab, int R, int Tp, const float2* __restrict__ x, int xstride,
+                                                   int lane) {
+    const int j = lane & 15, kq = lane >> 4;
+    DftTiles t;
+    t.r0 = t.i0 = t.r1 = t.i1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool two = R > 16, row0 = j < R, row1 = 16 + j < R;
+    for (int kk = 0; kk < R; kk += 4) {
+        const int k = kk + kq;
+        const bool vk = k < R;
+        const float2 xv = (vk && x) ? x[k * xstride] : make_float2(0.f, 0.f);
+        const float2 w0 = (vk && row0) ? tab[k * Tp + j] : make_float2(0.f, 0.f);
+        t.r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, xv.x, t.r0, 0, 0, 0);
+        t.i0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, xv.y, t.i0, 0, 0, 0);
+        if (two) {
+            const float2 w1 = (vk && row1) ? tab[k * Tp + 16 + j] : make_float2(0.f, 0.f);
+            t.r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, xv.x, t.r1, 0, 0, 0);
+            t.i1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, xv.y, t.i1, 0, 0, 0);
+            t.r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-w1.y, xv.y, t.r1, 0, 0, 0);
+            t.i1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, xv.x, t.i1, 0, 0, 0);
+        }
+        t.r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-w0.y, xv.y, t.r0, 0, 0, 0);
+        t.i0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, xv.x, t.i0, 0, 0, 0);
+    }
+    return t;
+}
 // complex LDS words of one row transform: two row buffers + the small-DFT tables (full A x A / B x B matrices, padded to
 // multiples of 4 columns, when both factors are <= 32; otherwise the A + B roots of unity)
 __host__ __device__ inline size_t pm_lds_elems(int P, int A, int B, bool onebuf = false) {
@@ -100,6 +135,16 @@ struct FusedIO {
     int norm_peak;        // OUT 4: divide by io.amax[frame] when it is > 0 and force the zero lag to exactly 1
 };
 
+#ifdef B4D_DIAG
+// Diagnostic build (never shipped, never timed as a whole): wall-clock stamps (100 MHz) of lane 0 at the phase boundaries.
+__device__ unsigned long long* g_pm_diag = nullptr;
+#define B4D_PM_STAMP(i)                                                                       \
+    do {                                                                                      \
+        if (g_pm_diag && threadIdx.x == 0 && DIAG_SEL) g_pm_diag[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define B4D_PM_STAMP(i) do { } while (0)
+#endif
 template <int P, int IN, int OUT, bool ONEBUF>
 __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const void* __restrict__ xin, float2* __restrict__ out, const float2* __restrict__ twN,
                                                  int A, int B, const float2* __restrict__ filt, int conj_io, float scale, FusedIO io) {
@@ -116,6 +161,14 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
     const int Ap = (A + 3) & ~3, Bp = (B + 3) & ~3;
     float2* tabB = tabA + (blocked ? A * Ap : A);
     const size_t s = blockIdx.x;
+#ifdef B4D_DIAG
+#ifndef B4D_DIAG_PM_IN
+#define B4D_DIAG_PM_IN 3
+#endif
+    constexpr bool DIAG_SEL = IN == B4D_DIAG_PM_IN;
+#endif
+    B4D_PM_STAMP(0);
+#ifndef B4D_EXP_PM_NOTAB   // timing-only switch: what the per-row table build costs
     if (blocked) {   // tabA[a][c] = W_A^{a c} (c < A, else 0), tabB[b][d] = W_B^{b d}
         for (int i = threadIdx.x; i < A * Ap; i += FT) {
             const int a = i / Ap, c = i % Ap;
@@ -129,6 +182,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
         for (int i = threadIdx.x; i < A; i += FT) tabA[i] = twN[(size_t)(N / A) * i];
         for (int i = threadIdx.x; i < B; i += FT) tabB[i] = twN[(size_t)(N / B) * i];
     }
+#endif
     float fsc = 1.f;
     bool fok = true;
     if (IN == 2 || IN == 3 || OUT == 1 || OUT == 3) {
@@ -140,6 +194,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
     const int pfr = (int)(s / hp), ppr = (int)(s % hp);
     const size_t prow0 = (size_t)pfr * io.rows + 2 * ppr;     // global index of the pair's first row
     const bool phas_b = 2 * ppr + 1 < io.rows;
+    B4D_PM_STAMP(1);
     // ---- radix-P butterflies over n1 (stride M) and the twiddle W_N^{n2 k1}
     for (int n2 = threadIdx.x; n2 < M; n2 += FT) {
         float2 v[P];
@@ -187,6 +242,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
         for (int k1 = 0; k1 < P; ++k1) buf0[k1 * M + n2] = k1 == 0 ? v[0] : cmulf(v[k1], twN[n2 * k1]);
     }
     __syncthreads();
+    B4D_PM_STAMP(2);
     // ---- DFT_A over a (n2 = B a + b), then the twiddle W_M^{b c} = W_N^{P b c}
 #ifndef B4D_EXP_PM_SKIP23
     if (onebuf) {    // one item per lane: compute into registers, barrier, write back into the same buffer
@@ -223,6 +279,34 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
             }
         }
     } else
+#ifndef B4D_EXP_PM_PACKED
+    if (blocked) {   // column n = (k1, b) = k1 * B + b; rows c
+        const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+        const int ncols = P * B;
+        for (int strip = threadIdx.x >> 6; strip * 16 < ncols; strip += FT / 64) {
+            const int n = strip * 16 + j;
+            const bool vn = n < ncols;
+            const int k1 = vn ? n / B : 0, b = vn ? n % B : 0;
+            float2 tw0[4], tw1[4];   // W_M^{b c} of this lane's outputs: in flight under the matrix products
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = 4 * kq + i;
+                tw0[i] = (vn && c < A) ? twN[(size_t)P * b * c] : make_float2(0.f, 0.f);
+                tw1[i] = (vn && c + 16 < A) ? twN[(size_t)P * b * (c + 16)] : make_float2(0.f, 0.f);
+            }
+            const DftTiles t = small_dft_mfma(tabA, A, Ap, vn ? buf0 + k1 * M + b : nullptr, B, lane);
+            if (vn) {
+                float2* dst = buf1 + k1 * M + b;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * kq + i;
+                    if (c < A) dst[c * B] = cmulf(make_float2(t.r0[i], t.i0[i]), tw0[i]);
+                    if (c + 16 < A) dst[(c + 16) * B] = cmulf(make_float2(t.r1[i], t.i1[i]), tw1[i]);
+                }
+            }
+        }
+    } else
+#endif
     if (blocked) {   // item = (k1, 4 outputs c, 2 columns b): per a two x reads and one 4-wide table row feed 8 complex MACs
         const int nCB = Ap / 4, nBB = (B + 1) / 2;
         for (int it = threadIdx.x; it < P * nCB * nBB; it += FT) {
@@ -291,6 +375,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
         }
         }
     __syncthreads();
+    B4D_PM_STAMP(3);
     // ---- DFT_B over b (k2 = c + A d) -> natural order k = k1 + P (c + A d) in buf0
     if (onebuf) {
         const int nCP = (A + 1) / 2, nDB = Bp / 4;
@@ -327,6 +412,26 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
             }
         }
     } else
+#ifndef B4D_EXP_PM_PACKED
+    if (blocked) {   // column n = (c, k1) = c * P + k1 (natural output order k1 + P (c + A d) = n + P A d); rows d
+        const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+        const int ncols = P * A;
+        for (int strip = threadIdx.x >> 6; strip * 16 < ncols; strip += FT / 64) {
+            const int n = strip * 16 + j;
+            const bool vn = n < ncols;
+            const int c = vn ? n / P : 0, k1 = vn ? n % P : 0;
+            const DftTiles t = small_dft_mfma(tabB, B, Bp, vn ? buf1 + k1 * M + c * B : nullptr, 1, lane);
+            if (vn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int d = 4 * kq + i;
+                    if (d < B) buf0[n + P * A * d] = make_float2(t.r0[i], t.i0[i]);
+                    if (d + 16 < B) buf0[n + P * A * (d + 16)] = make_float2(t.r1[i], t.i1[i]);
+                }
+            }
+        }
+    } else
+#endif
     if (blocked) {   // item = (k1, 2 rows c, 4 outputs d)
         const int nCP = (A + 1) / 2, nDB = Bp / 4;
         for (int it = threadIdx.x; it < P * nCP * nDB; it += FT) {
@@ -397,6 +502,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
         }
     __syncthreads();
 #endif
+    B4D_PM_STAMP(4);
     if (OUT == 4) {
         const float pk = io.norm_peak ? io.amax[pfr] : 0.f;
         const bool unit = io.norm_peak && pk > 0.f;
@@ -414,6 +520,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
                 orow[(x + N / 2) % N] = v;
             }
         }
+        B4D_PM_STAMP(5);
         return;
     }
     if (OUT == 2) {
@@ -424,6 +531,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
             oa[k] = make_float2(0.5f * (z.x + w.x), 0.5f * (z.y - w.y));
             if (has_b) oa[io.half + k] = make_float2(0.5f * (z.y + w.y), 0.5f * (w.x - z.x));
         }
+        B4D_PM_STAMP(5);
         return;
     }
     if (OUT == 3) {
@@ -438,6 +546,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
                 io.crop[(size_t)y * io.w + x] = fok ? v * fsc : 0.f;
             }
         }
+        B4D_PM_STAMP(5);
         return;
     }
     if (OUT == 1) {
@@ -448,6 +557,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
             if (io.clip) v = (v > 1.f ? 1.f : (v < -1.f ? -1.f : v))   /* np.clip: NaN stays NaN */;
             io.crop[(size_t)y * io.w + x] = fok ? v * fsc : 0.f;
         }
+        B4D_PM_STAMP(5);
         return;
     }
     for (int k = threadIdx.x; k < N; k += FT) {
@@ -456,6 +566,7 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
         if (conj_io) v.y = -v.y;
         out[s * (size_t)N + k] = make_float2(v.x * scale, v.y * scale);
     }
+    B4D_PM_STAMP(5);
 }
 
 // amax[0] = max of the `nparts` partial maxima (one wave)
@@ -1116,3 +1227,10 @@ int b4d_richardson_lucy(const float* frames, int batch, int h, int w, const floa
 }
 
 }  // extern "C"
+
+#ifdef B4D_DIAG
+extern "C" int b4d_debug_set_pm_diag(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(b4d::g_pm_diag), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
