@@ -146,7 +146,8 @@ __device__ unsigned long long* g_pm_diag = nullptr;
 #define B4D_PM_STAMP(i) do { } while (0)
 #endif
 template <int P, int IN, int OUT, bool ONEBUF>
-__global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const void* __restrict__ xin, float2* __restrict__ out, const float2* __restrict__ twN,
+// two 1024-lane workgroups per CU need <= 64 VGPRs: asked for explicitly where the radix-P stage leaves room (P <= 8)
+__global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX, (!ONEBUF && P <= 8) ? 8 : 1) k_pm_fused(const void* __restrict__ xin, float2* __restrict__ out, const float2* __restrict__ twN,
                                                  int A, int B, const float2* __restrict__ filt, int conj_io, float scale, FusedIO io) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     constexpr bool onebuf = ONEBUF;
@@ -204,24 +205,29 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
             if (IN == 3) {
                 int x = M * n1 + n2 - io.px;
                 x = x < 0 ? -x : (x >= io.w ? 2 * io.w - 2 - x : x);
+                // loads and divisions are unconditional (clamped row) and masked afterwards: a load under a branch would wait
+                // for its data before the next one is issued (measured: 16 serial round trips, 7.5 us per row)
                 float q[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int row = 2 * (int)s + e;
+                    const int row = min(2 * (int)s + e, io.rows - 1);
                     int y = row - io.py;
                     y = y < 0 ? -y : (y >= io.h ? 2 * io.h - 2 - y : y);
-                    q[e] = (fok && row < io.rows) ? io.frame[(size_t)y * io.w + x] / fsc : 0.f;
+                    const float d = io.frame[(size_t)y * io.w + x] / fsc;
+                    q[e] = (fok && 2 * (int)s + e < io.rows) ? d : 0.f;
                 }
                 v[n1] = make_float2(q[0], q[1]);
             } else if (IN == 5) {
                 const int idx = M * n1 + n2;
                 const float* pa = static_cast<const float*>(xin) + prow0 * N;
-                v[n1] = make_float2(pa[idx], phas_b ? pa[N + idx] : 0.f);
+                const float qb = (phas_b ? pa + N : pa)[idx];   // unconditional load, masked below
+                v[n1] = make_float2(pa[idx], phas_b ? qb : 0.f);
             } else if (IN == 4) {
                 const int idx = M * n1 + n2, j = idx <= N / 2 ? idx : N - idx;
                 const float2* pa = static_cast<const float2*>(xin) + prow0 * io.half;
                 const float2 fa = pa[j];
-                const float2 fb = phas_b ? pa[io.half + j] : make_float2(0.f, 0.f);
+                float2 fb = (phas_b ? pa + io.half : pa)[j];   // unconditional load, masked below
+                if (!phas_b) fb = make_float2(0.f, 0.f);
                 // Ga + i Gb, Hermitian-extended beyond N/2; then the inverse's input conjugation
                 const float2 z = idx <= N / 2 ? make_float2(fa.x - fb.y, fa.y + fb.x) : make_float2(fa.x + fb.y, fb.x - fa.y);
                 v[n1] = make_float2(z.x, -z.y);
@@ -229,7 +235,8 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
                 int y = (int)s - io.py, x = M * n1 + n2 - io.px;
                 y = y < 0 ? -y : (y >= io.h ? 2 * io.h - 2 - y : y);
                 x = x < 0 ? -x : (x >= io.w ? 2 * io.w - 2 - x : x);
-                v[n1] = make_float2(fok ? io.frame[(size_t)y * io.w + x] / fsc : 0.f, 0.f);
+                const float d = io.frame[(size_t)y * io.w + x] / fsc;
+                v[n1] = make_float2(fok ? d : 0.f, 0.f);
             } else if (IN == 1) {
                 v[n1] = make_float2(static_cast<const float*>(xin)[i], 0.f);
             } else {
@@ -237,9 +244,14 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
                 v[n1] = conj_io ? make_float2(q.x, -q.y) : q;
             }
         }
+#ifdef B4D_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        B4D_PM_STAMP(6);
+#endif
         Dft<P>::run(v);
 #pragma unroll
         for (int k1 = 0; k1 < P; ++k1) buf0[k1 * M + n2] = k1 == 0 ? v[0] : cmulf(v[k1], twN[n2 * k1]);
+        B4D_PM_STAMP(7);
     }
     __syncthreads();
     B4D_PM_STAMP(2);
@@ -291,8 +303,8 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = 4 * kq + i;
-                tw0[i] = (vn && c < A) ? twN[(size_t)P * b * c] : make_float2(0.f, 0.f);
-                tw1[i] = (vn && c + 16 < A) ? twN[(size_t)P * b * (c + 16)] : make_float2(0.f, 0.f);
+                tw0[i] = twN[(size_t)P * b * min(c, A - 1)];          // unconditional (clamped): loads under a branch serialise
+                tw1[i] = twN[(size_t)P * b * min(c + 16, A - 1)];
             }
             const DftTiles t = small_dft_mfma(tabA, A, Ap, vn ? buf0 + k1 * M + b : nullptr, B, lane);
             if (vn) {
@@ -560,11 +572,20 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX) k_pm_fused(const 
         B4D_PM_STAMP(5);
         return;
     }
-    for (int k = threadIdx.x; k < N; k += FT) {
-        float2 v = buf0[k];
-        if (filt) v = cmulf(v, filt[(io.filt_bcast ? 0 : s * (size_t)N) + k]);
-        if (conj_io) v.y = -v.y;
-        out[s * (size_t)N + k] = make_float2(v.x * scale, v.y * scale);
+    const float2* frow = filt ? filt + (io.filt_bcast ? 0 : s * (size_t)N) : nullptr;
+    for (int k0 = threadIdx.x; k0 < N; k0 += 4 * FT) {   // four filter loads in flight per lane (clamped index, masked store)
+        float2 f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = frow ? frow[min(k0 + u * FT, N - 1)] : make_float2(1.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * FT;
+            if (k >= N) break;
+            float2 v = buf0[k];
+            if (frow) v = cmulf(v, f[u]);
+            if (conj_io) v.y = -v.y;
+            out[s * (size_t)N + k] = make_float2(v.x * scale, v.y * scale);
+        }
     }
     B4D_PM_STAMP(5);
 }
@@ -728,6 +749,9 @@ __global__ void __launch_bounds__(256) k_rl_crop(const float* __restrict__ est, 
 
 using namespace b4d;
 
+#ifndef B4D_WIENER_LANES
+#define B4D_WIENER_LANES 2
+#endif
 struct b4d_wiener {
     std::recursive_mutex mu;     // host-side re-entrancy (several host threads, one plan)
     int h, w, py, px, H, W;      // frame, half kernel, padded sizes
@@ -743,6 +767,20 @@ struct b4d_wiener {
     float2* c = nullptr;
     float* padded = nullptr;     // (H, W) real
     float* amax = nullptr;       // 256 partial maxima
+    // further sets of work buffers + internal streams (lazily created by the first multi-frame call): consecutive frames
+    // run on alternate streams, so one frame's row transforms fill the chip while another's last partial round of
+    // workgroups (2052 rows on 512 resident workgroups: 4 full rounds + 4 stragglers) and its HBM bursts drain
+    struct Lane {
+        float2* a = nullptr;
+        float2* b = nullptr;
+        float2* c = nullptr;
+        float* padded = nullptr;
+        float* amax = nullptr;
+        hipStream_t st = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    Lane lane[B4D_WIENER_LANES];   // lane[0] aliases a, b, c, padded, amax
+    hipEvent_t fork = nullptr;
 };
 
 static void split_pm(int n, int* P, int* M) {
@@ -1044,6 +1082,15 @@ int b4d_wiener_destroy(b4d_wiener* p) {
     for (void* q : {(void*)p->twx, (void*)p->twy, (void*)p->dmx, (void*)p->dmy, (void*)p->filt, (void*)p->a, (void*)p->b, (void*)p->c,
                     (void*)p->padded, (void*)p->amax})
         if (q) (void)hipFree(q);
+    for (int l = 0; l < B4D_WIENER_LANES; ++l) {
+        b4d_wiener::Lane& L = p->lane[l];
+        if (l > 0)
+            for (void* q : {(void*)L.a, (void*)L.b, (void*)L.c, (void*)L.padded, (void*)L.amax})
+                if (q) (void)hipFree(q);
+        if (L.st) (void)hipStreamDestroy(L.st);
+        if (L.done) (void)hipEventDestroy(L.done);
+    }
+    if (p->fork) (void)hipEventDestroy(p->fork);
     delete p;
     return B4D_OK;
 }
@@ -1129,62 +1176,95 @@ int b4d_wiener_create(int h, int w, const float* psf_host, int ky, int kx, float
     return B4D_OK;
 }
 
+// one frame through pad/normalise -> rows -> columns x filter -> inverse, on stream st with the work buffers of `lane`
+static int wiener_frame(b4d_wiener* p, int lane, const float* f, float* o, int clip, hipStream_t st) {
+    const b4d_wiener::Lane& L = p->lane[lane];
+    float2* const wa = lane ? L.a : p->a;
+    float2* const wb = lane ? L.b : p->b;
+    float2* const wc = lane ? L.c : p->c;
+    float* const wpad = lane ? L.padded : p->padded;
+    float* const wmax = lane ? L.amax : p->amax;
+    const size_t fp = (size_t)p->h * p->w, n = (size_t)p->H * p->W;
+    const float inv = 1.0f / (float)n;
+    hipLaunchKernelGGL(k_nanabsmax, dim3(256), dim3(1024), 0, st, f, fp, wmax);
+    hipLaunchKernelGGL(k_absmax_final, dim3(1), dim3(64), 0, st, wmax, 256);
+    B4D_HIP(hipGetLastError());
+    FusedIO io{f, o, wmax, p->h, p->w, p->py, p->px, clip, p->W / 2 + 1, p->H};
+    int rc;
+    if (p->Ax && p->Ay) {
+        // real input: rows ride in pairs (a + i b) through one complex transform, only the W/2 + 1 independent
+        // columns go through the column passes (the filter of a real PSF is Hermitian), the inverse row pass
+        // rebuilds each pair from its two half rows
+        const int Wh = p->W / 2 + 1, Hp = (p->H + 1) / 2;
+        if ((rc = dft_rows(nullptr, true, wa, wb, wc, Hp, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st, p->Ax, p->Bx, &io, 3, 0))) return rc;
+        if ((rc = transpose_c(wc, wa, p->H, Wh, st))) return rc;
+        if ((rc = dft_rows(wa, false, wb, wc, wa, Wh, p->Py, p->My, p->twy, p->dmy, false, p->filt, 1.f, st, p->Ay, p->By))) return rc;
+        if ((rc = dft_rows(wa, false, wb, wc, wa, Wh, p->Py, p->My, p->twy, p->dmy, true, nullptr, 1.f, st, p->Ay, p->By))) return rc;
+        if ((rc = transpose_c(wa, wb, Wh, p->H, st))) return rc;
+        return dft_rows(wb, false, wc, wa, wc, Hp, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st, p->Ax, p->Bx, &io, 4, 0);
+    }
+    // forward: rows (frame -> c), transpose (c -> a), columns + filter (a -> a), all in the transposed domain after that
+    if (p->Ax) {  // reflect padding and normalisation folded into the row pass's loads
+        rc = dft_rows(nullptr, true, wa, wb, wc, p->H, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st, p->Ax, p->Bx, &io, 2, 0);
+    } else {
+        hipLaunchKernelGGL(k_pad_reflect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, p->h, p->w, p->py, p->px, wmax, 1, wpad);
+        B4D_HIP(hipGetLastError());
+        rc = dft_rows(wpad, true, wa, wb, wc, p->H, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st);
+    }
+    if (rc) return rc;
+    if ((rc = transpose_c(wc, wa, p->H, p->W, st))) return rc;
+    if ((rc = dft_rows(wa, false, wb, wc, wa, p->W, p->Py, p->My, p->twy, p->dmy, false, p->filt, 1.f, st, p->Ay, p->By))) return rc;
+    // inverse: columns (a -> a), transpose (a -> b), rows (b -> b) with the 1/(H W) factor
+    if ((rc = dft_rows(wa, false, wb, wc, wa, p->W, p->Py, p->My, p->twy, p->dmy, true, nullptr, 1.f, st, p->Ay, p->By))) return rc;
+    if ((rc = transpose_c(wa, wb, p->W, p->H, st))) return rc;
+    if (p->Ax)   // clip, rescale and crop folded into the last pass's stores
+        return dft_rows(wb, false, wc, wa, wb, p->H, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st, p->Ax, p->Bx, &io, 0, 1);
+    if ((rc = dft_rows(wb, false, wc, wa, wb, p->H, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st))) return rc;
+    hipLaunchKernelGGL(k_crop_out, dim3((unsigned)((fp + 255) / 256)), dim3(256), 0, st, wb, p->h, p->w, p->py, p->px, wmax, 1, clip, o);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+// lanes 1..: work buffers; every lane: a non-blocking stream and its join event
+static int wiener_lanes(b4d_wiener* p) {
+    if (p->fork) return B4D_OK;
+    const size_t n = (size_t)p->H * p->W;
+    for (int l = 0; l < B4D_WIENER_LANES; ++l) {
+        b4d_wiener::Lane& L = p->lane[l];
+        if (l > 0) {
+            B4D_HIP(hipMalloc((void**)&L.a, sizeof(float2) * n));
+            B4D_HIP(hipMalloc((void**)&L.b, sizeof(float2) * n));
+            B4D_HIP(hipMalloc((void**)&L.c, sizeof(float2) * n));
+            B4D_HIP(hipMalloc((void**)&L.padded, sizeof(float) * n));
+            B4D_HIP(hipMalloc((void**)&L.amax, sizeof(float) * 256));
+        }
+        B4D_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        B4D_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    }
+    B4D_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+    return B4D_OK;
+}
+
 int b4d_wiener_apply(b4d_wiener* p, const float* frames, int batch, float* out, int clip, void* stream) {
     if (!p) return fail(B4D_EINVAL, "null argument");
     std::lock_guard<std::recursive_mutex> lk(p->mu);
     if (!p || !frames || !out) return fail(B4D_EINVAL, "null argument");
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
     hipStream_t st = (hipStream_t)stream;
-    const size_t fp = (size_t)p->h * p->w, n = (size_t)p->H * p->W;
-    const float inv = 1.0f / (float)n;
-    for (int b = 0; b < batch; ++b) {
-        const float* f = frames + b * fp;
-        hipLaunchKernelGGL(k_nanabsmax, dim3(256), dim3(1024), 0, st, f, fp, p->amax);
-        hipLaunchKernelGGL(k_absmax_final, dim3(1), dim3(64), 0, st, p->amax, 256);
-        B4D_HIP(hipGetLastError());
-        FusedIO io{f, out + b * fp, p->amax, p->h, p->w, p->py, p->px, clip, p->W / 2 + 1, p->H};
-        int rc;
-        if (p->Ax && p->Ay) {
-            // real input: rows ride in pairs (a + i b) through one complex transform, only the W/2 + 1 independent
-            // columns go through the column passes (the filter of a real PSF is Hermitian), the inverse row pass
-            // rebuilds each pair from its two half rows
-            const int Wh = p->W / 2 + 1, Hp = (p->H + 1) / 2;
-            if ((rc = dft_rows(nullptr, true, p->a, p->b, p->c, Hp, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st, p->Ax, p->Bx, &io, 3, 0)))
-                return rc;
-            if ((rc = transpose_c(p->c, p->a, p->H, Wh, st))) return rc;
-            if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, Wh, p->Py, p->My, p->twy, p->dmy, false, p->filt, 1.f, st, p->Ay, p->By))) return rc;
-            if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, Wh, p->Py, p->My, p->twy, p->dmy, true, nullptr, 1.f, st, p->Ay, p->By))) return rc;
-            if ((rc = transpose_c(p->a, p->b, Wh, p->H, st))) return rc;
-            if ((rc = dft_rows(p->b, false, p->c, p->a, p->c, Hp, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st, p->Ax, p->Bx, &io, 4, 0)))
-                return rc;
-            continue;
-        }
-        // forward: rows (frame -> c), transpose (c -> a), columns + filter (a -> a), all in the transposed domain after that
-        if (p->Ax) {  // reflect padding and normalisation folded into the row pass's loads
-            rc = dft_rows(nullptr, true, p->a, p->b, p->c, p->H, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st, p->Ax, p->Bx, &io, 2, 0);
-        } else {
-            hipLaunchKernelGGL(k_pad_reflect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, p->h, p->w, p->py, p->px, p->amax, 1,
-                               p->padded);
-            B4D_HIP(hipGetLastError());
-            rc = dft_rows(p->padded, true, p->a, p->b, p->c, p->H, p->Px, p->Mx, p->twx, p->dmx, false, nullptr, 1.f, st);
-        }
-        if (rc) return rc;
-        if ((rc = transpose_c(p->c, p->a, p->H, p->W, st))) return rc;
-        if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, p->W, p->Py, p->My, p->twy, p->dmy, false, p->filt, 1.f, st, p->Ay, p->By))) return rc;
-        // inverse: columns (a -> a), transpose (a -> b), rows (b -> b) with the 1/(H W) factor
-        if ((rc = dft_rows(p->a, false, p->b, p->c, p->a, p->W, p->Py, p->My, p->twy, p->dmy, true, nullptr, 1.f, st, p->Ay, p->By))) return rc;
-        if ((rc = transpose_c(p->a, p->b, p->W, p->H, st))) return rc;
-        if (p->Ax) {  // clip, rescale and crop folded into the last pass's stores
-            if ((rc = dft_rows(p->b, false, p->c, p->a, p->b, p->H, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st, p->Ax, p->Bx, &io, 0, 1)))
-                return rc;
-        } else {
-            if ((rc = dft_rows(p->b, false, p->c, p->a, p->b, p->H, p->Px, p->Mx, p->twx, p->dmx, true, nullptr, inv, st))) return rc;
-            hipLaunchKernelGGL(k_crop_out, dim3((unsigned)((fp + 255) / 256)), dim3(256), 0, st, p->b, p->h, p->w, p->py, p->px, p->amax, 1,
-                               clip, out + b * fp);
-            B4D_HIP(hipGetLastError());
-        }
+    const size_t fp = (size_t)p->h * p->w;
+    if (batch == 1) return wiener_frame(p, 0, frames, out, clip, st);
+    int rc = wiener_lanes(p);
+    if (rc) return rc;
+    // fork: the lanes start after everything already queued on the caller's stream; join: the caller's stream waits for all
+    const int nl = std::min(batch, B4D_WIENER_LANES);
+    B4D_HIP(hipEventRecord(p->fork, st));
+    for (int l = 0; l < nl; ++l) B4D_HIP(hipStreamWaitEvent(p->lane[l].st, p->fork, 0));
+    for (int b = 0; b < batch && rc == B4D_OK; ++b) rc = wiener_frame(p, b % nl, frames + b * fp, out + b * fp, clip, p->lane[b % nl].st);
+    for (int l = 0; l < nl; ++l) {
+        B4D_HIP(hipEventRecord(p->lane[l].done, p->lane[l].st));
+        B4D_HIP(hipStreamWaitEvent(st, p->lane[l].done, 0));
     }
-    return B4D_OK;
+    return rc;
 }
 
 int b4d_richardson_lucy(const float* frames, int batch, int h, int w, const float* psf_host, int ky, int kx, int num_iter,

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, ".")
 from barc4dip_amd import _ffi, synth  # noqa: E402
 
-_ffi._lib = _ffi.load_library("barc4dip_amd/csrc/libb4d_diag.so")
+_ffi._lib = _ffi.load_library(sys.argv[2] if len(sys.argv) > 2 else "barc4dip_amd/csrc/libb4d_diag.so")
 from barc4dip_amd.preprocessing import deconvolve_psf  # noqa: E402
 
 lib = _ffi._lib
@@ -27,6 +27,9 @@ d = diag.cpu().numpy().astype(np.float64)
 d = d[d[:, 0] > 0]
 t0 = d[:, 0].min()
 us = (d[:, :6] - t0) / 100.0          # wall_clock64: 100 MHz
+if d[:, 6].max() > 0:
+    print("inside load+radixP (us): inputs arrived %.2f, butterflies + twiddles + LDS writes %.2f, wait at the barrier %.2f" % (
+        np.median(d[:, 6] - d[:, 1]) / 100, np.median(d[:, 7] - d[:, 6]) / 100, np.median(d[:, 2] - d[:, 7]) / 100))
 names = ["tables", "load+radixP", "DFT_A", "DFT_B", "store issue"]
 dt = np.diff(us, axis=1)
 print("workgroups recorded:", len(d), " kernel span %.1f us" % (us[:, 5].max()))
