@@ -190,7 +190,9 @@ int b4d_psd_stats(const float* psd, int batch, int ny, int nx, double* out, void
  *   regularisation `balance` (skimage.restoration.wiener, Laplacian regulariser).  The padded size (h + 2*(ky/2),
  *   w + 2*(kx/2)) may be any integer whose odd part is <= 4200 (4096 + 8 = 4104 = 8 * 513 for sigma 1.5).
  * apply: per frame reflect-pad, divide by max|.|, filter in the Fourier domain of the padded size, clip to [-1, 1]
- *   (if clip), rescale, crop -> out (batch, h, w) float32.                                                      */
+ *   (if clip), rescale, crop -> out (batch, h, w) float32.  Ordering is that of `stream`: a call with batch > 1 runs
+ *   alternate frames on two plan-owned streams that wait for the work already queued on `stream` and that `stream`
+ *   waits for before anything queued after the call (no host synchronisation).                                  */
 typedef struct b4d_wiener b4d_wiener;
 int b4d_wiener_create(int h, int w, const float* psf, int ky, int kx, float balance, b4d_wiener** out);
 int b4d_wiener_apply(b4d_wiener* plan, const float* frames, int batch, float* out, int clip, void* stream);
