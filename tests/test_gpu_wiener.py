@@ -53,6 +53,32 @@ def test_stack_balance_and_errors(pp):
         pp.deconvolve_psf(stack, sigma=1.0, method="uw")
 
 
+def test_stack_frames_on_two_streams_keep_the_callers_order(pp):
+    """A multi-frame call runs alternate frames on two plan-owned streams (include/b4d.h): each frame must equal the
+    single-frame call bit for bit, on the default stream and on a side stream with consumers queued right behind it."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    stack = torch.from_numpy(synth.speckle_stack(5, 512, seed0=70)[:, :500, :404].copy()).to(dev)
+    singles = torch.stack([pp.deconvolve_psf(stack[t], sigma=1.5, return_tensors=True) for t in range(5)])
+    torch.cuda.synchronize()
+    for _ in range(3):
+        got = pp.deconvolve_psf(stack, sigma=1.5, return_tensors=True)
+        total = got.sum(dtype=torch.float64)         # queued on the same stream right after the call
+        assert torch.equal(got, singles)
+        assert float(total) == float(singles.sum(dtype=torch.float64))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        scaled = stack * 2.0                          # producer queued on the side stream just before the call
+        got = pp.deconvolve_psf(scaled, sigma=1.5, return_tensors=True)
+        halves = got * 0.5                            # consumer queued behind it
+    side.synchronize()
+    ref = torch.stack([pp.deconvolve_psf(scaled[t], sigma=1.5, return_tensors=True) for t in range(5)])
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref) and torch.equal(halves, ref * 0.5)
+
+
 @pytest.mark.parametrize("shape,sigma,iters", [((60, 52), 1.5, 12), ((130, 200), (1.0, 2.0), 30), ((512, 512), 1.5, 8)])
 def test_richardson_lucy_vs_oracle(pp, shape, sigma, iters):
     """method="rl" (filters.py:270-277) against the float32 oracle of the published algorithm (parity with scikit-image
