@@ -220,14 +220,12 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX, (!ONEBUF && P <= 
             } else if (IN == 5) {
                 const int idx = M * n1 + n2;
                 const float* pa = static_cast<const float*>(xin) + prow0 * N;
-                const float qb = (phas_b ? pa + N : pa)[idx];   // unconditional load, masked below
-                v[n1] = make_float2(pa[idx], phas_b ? qb : 0.f);
+                v[n1] = make_float2(pa[idx], phas_b ? pa[N + idx] : 0.f);
             } else if (IN == 4) {
                 const int idx = M * n1 + n2, j = idx <= N / 2 ? idx : N - idx;
                 const float2* pa = static_cast<const float2*>(xin) + prow0 * io.half;
                 const float2 fa = pa[j];
-                float2 fb = (phas_b ? pa + io.half : pa)[j];   // unconditional load, masked below
-                if (!phas_b) fb = make_float2(0.f, 0.f);
+                const float2 fb = phas_b ? pa[io.half + j] : make_float2(0.f, 0.f);
                 // Ga + i Gb, Hermitian-extended beyond N/2; then the inverse's input conjugation
                 const float2 z = idx <= N / 2 ? make_float2(fa.x - fb.y, fa.y + fb.x) : make_float2(fa.x + fb.y, fb.x - fa.y);
                 v[n1] = make_float2(z.x, -z.y);
@@ -572,20 +570,11 @@ __global__ void __launch_bounds__(ONEBUF ? FT_ONEBUF : FT_MAX, (!ONEBUF && P <= 
         B4D_PM_STAMP(5);
         return;
     }
-    const float2* frow = filt ? filt + (io.filt_bcast ? 0 : s * (size_t)N) : nullptr;
-    for (int k0 = threadIdx.x; k0 < N; k0 += 4 * FT) {   // four filter loads in flight per lane (clamped index, masked store)
-        float2 f[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f[u] = frow ? frow[min(k0 + u * FT, N - 1)] : make_float2(1.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * FT;
-            if (k >= N) break;
-            float2 v = buf0[k];
-            if (frow) v = cmulf(v, f[u]);
-            if (conj_io) v.y = -v.y;
-            out[s * (size_t)N + k] = make_float2(v.x * scale, v.y * scale);
-        }
+    for (int k = threadIdx.x; k < N; k += FT) {
+        float2 v = buf0[k];
+        if (filt) v = cmulf(v, filt[(io.filt_bcast ? 0 : s * (size_t)N) + k]);
+        if (conj_io) v.y = -v.y;
+        out[s * (size_t)N + k] = make_float2(v.x * scale, v.y * scale);
     }
     B4D_PM_STAMP(5);
 }
