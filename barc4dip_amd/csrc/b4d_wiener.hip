@@ -786,7 +786,7 @@ static void split_ab(int P, int M, int* A, int* B) {
         if (M % f == 0) best = f;
     const int a = M / best, b = best;
     const size_t lds = sizeof(float2) * pm_lds_elems(P, a, b);
-    if (a + b <= 128 && lds <= 150 * 1024) {
+    if (a + b <= 320 && lds <= 150 * 1024) {   // beyond ~300 complex MACs per element the chirp-z / DFT-matrix routes win
         *A = a;
         *B = b;
     } else {
