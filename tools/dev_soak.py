@@ -8,7 +8,8 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 t0 = time.time()
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
-    ny, nx = int(rng.integers(2, 1400)), int(rng.integers(2, 1400))
+    HI = int(sys.argv[3]) if len(sys.argv) > 3 else 1400
+    ny, nx = int(rng.integers(2, HI)), int(rng.integers(2, HI))
     if rng.random() < 0.2:
         ny = int(2 ** rng.integers(6, 11))
     if not _ffi.supported(ny, nx):
