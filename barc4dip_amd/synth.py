@@ -57,7 +57,9 @@ def speckle_stack_device(t: int, n: int, *, seed0: int = 1234, device="cuda", ch
                          pupil_div: int = 8, mean: float = 1000.0):
     """(t, n, n) float32 speckle stack generated in HBM (same statistics as `speckle_frame`,
     different random stream: torch's counter-based generator).  Used for bench inputs only;
-    parity tests use the host generators."""
+    parity tests use the host generators.  The generator itself calls torch.fft (rocFFT shows up as
+    `fft_rtc_*` kernels in profiles of the input set-up): it builds test data outside every timed region and is
+    not part of the product path, which has no rocFFT dependency."""
     import torch
 
     g = torch.Generator(device=device)
