@@ -71,7 +71,7 @@ def cfg4(T=256, n=2048, steps=5):  # 256-frame shard fits the default test box q
                       "cpu_sample": "32 frames, NumPy float64 mean/var"}), flush=True)
 
 
-def cfg5(T=8, n=4096, sigma=1.5, steps=3):
+def cfg5(T=32, n=4096, sigma=1.5, steps=3):   # T = 32 on one GPU
     from barc4dip_amd.preprocessing import deconvolve_psf
 
     dev = synth.speckle_stack_device(T, n)
