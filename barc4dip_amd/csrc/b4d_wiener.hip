@@ -650,10 +650,26 @@ __global__ void __launch_bounds__(256) k_crop_out(const float2* __restrict__ z, 
 __global__ void __launch_bounds__(1024) k_nanabsmax(const float* __restrict__ x, size_t n, float* __restrict__ part) {
     __shared__ float sh[16];
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float a = fabsf(x[i]);
+    auto take = [&](float v) {
+        const float a = fabsf(v);
         if (a == a) m = fmaxf(m, a);
+    };
+    // 16-byte loads, four per lane in flight (a frame is one stream: the scalar grid-stride loop was latency-bound)
+    const size_t n4 = ((reinterpret_cast<size_t>(x) & 15) == 0) ? n / 4 : 0, stride = (size_t)gridDim.x * blockDim.x;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        take(a.x); take(a.y); take(a.z); take(a.w);
+        take(b.x); take(b.y); take(b.z); take(b.w);
+        take(c.x); take(c.y); take(c.z); take(c.w);
+        take(d.x); take(d.y); take(d.z); take(d.w);
     }
+    for (; i < n4; i += stride) {
+        const float4 a = x4[i];
+        take(a.x); take(a.y); take(a.z); take(a.w);
+    }
+    for (size_t j = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) take(x[j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
