@@ -1236,15 +1236,15 @@ static int wiener_lanes(b4d_wiener* p) {
     const size_t n = (size_t)p->H * p->W;
     for (int l = 0; l < B4D_WIENER_LANES; ++l) {
         b4d_wiener::Lane& L = p->lane[l];
-        if (l > 0) {
-            B4D_HIP(hipMalloc((void**)&L.a, sizeof(float2) * n));
-            B4D_HIP(hipMalloc((void**)&L.b, sizeof(float2) * n));
-            B4D_HIP(hipMalloc((void**)&L.c, sizeof(float2) * n));
-            B4D_HIP(hipMalloc((void**)&L.padded, sizeof(float) * n));
-            B4D_HIP(hipMalloc((void**)&L.amax, sizeof(float) * 256));
+        if (l > 0) {   // each step only if still missing: a call that failed half-way (out of memory) can be repeated
+            if (!L.a) B4D_HIP(hipMalloc((void**)&L.a, sizeof(float2) * n));
+            if (!L.b) B4D_HIP(hipMalloc((void**)&L.b, sizeof(float2) * n));
+            if (!L.c) B4D_HIP(hipMalloc((void**)&L.c, sizeof(float2) * n));
+            if (!L.padded) B4D_HIP(hipMalloc((void**)&L.padded, sizeof(float) * n));
+            if (!L.amax) B4D_HIP(hipMalloc((void**)&L.amax, sizeof(float) * 256));
         }
-        B4D_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
-        B4D_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        if (!L.st) B4D_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        if (!L.done) B4D_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     }
     B4D_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     return B4D_OK;
