@@ -17,6 +17,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "b4d_timing_only.hpp"
+
 namespace b4d {
 
 // Complex arithmetic on the packed-FP32 pipe (v_pk_add/mul/fma_f32: both halves of a complex value per instruction,

@@ -11,7 +11,7 @@ std::string& last_error() {
 
 extern "C" {
 
-const char* b4d_version(void) { return "b4d 0.1.0 (gfx950)"; }
+const char* b4d_version(void) { return "b4d 0.2.0 (gfx950)" B4D_VERSION_SUFFIX; }
 const char* b4d_last_error(void) { return last_error().c_str(); }
 static bool large_ok(int ny, int nx) {
     return ny >= 2 && nx >= 2 && ny <= 8192 && nx <= 8192 && (size_t)ny * nx <= ((size_t)1 << 26) && pm_supported(ny) && pm_supported(nx);

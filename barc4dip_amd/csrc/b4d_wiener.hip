@@ -13,6 +13,7 @@
 // multiply, and the same two passes back with conjugated inputs/outputs.
 // Parity: UNPINNED (scikit-image is not installable here); oracle/wiener_np.py restates the published algorithm.
 #include "b4d_fft2d.hpp"
+#include "b4d_wiener_mr.hpp"
 
 // complex GEMM of b4d_general.hip
 int b4d_cgemm(const void* A, bool a_real, long long sA, int conj_a, const void* B, bool b_real, long long sB, int conj_b,
@@ -786,7 +787,28 @@ struct b4d_wiener {
     };
     Lane lane[B4D_WIENER_LANES];   // lane[0] aliases a, b, c, padded, amax
     hipEvent_t fork = nullptr;
+    // mixed-radix route (b4d_wiener_mr.hip): both padded sides have a compiled three-radix kernel
+    bool mr = false;
+    WmrGeom geom{};
+    float2* mr_filt = nullptr;   // (Wh, Hp) transposed half filter
+    float2* mr_T = nullptr;      // (mr_cap, Wh, Hp) transposed half spectra of the frames of one launch
+    float* mr_amax = nullptr;    // (mr_cap * (hp + 1)): max|frame| per frame, then the pair maxima
+    int mr_cap = 0;
 };
+
+// frames per launch of the mixed-radix route: enough rows to hide the ragged tail of a launch (2052 pairs on 1024
+// resident workgroups), few enough that the spectra of a launch (67 MB per 4k frame) stay in the 256-MiB infinity cache
+#ifndef B4D_WIENER_FPL
+#define B4D_WIENER_FPL 2
+#endif
+static int wiener_fpl() {
+    static const int v = [] {
+        const char* e = getenv("B4D_WIENER_FPL");   // tuning aid (tools/dev_cfg5.py); results do not depend on it
+        const int n = e ? atoi(e) : 0;
+        return n >= 1 && n <= 64 ? n : B4D_WIENER_FPL;
+    }();
+    return v;
+}
 
 static void split_pm(int n, int* P, int* M) {
     int p = 1;
@@ -1085,7 +1107,7 @@ extern "C" {
 int b4d_wiener_destroy(b4d_wiener* p) {
     if (!p) return B4D_OK;
     for (void* q : {(void*)p->twx, (void*)p->twy, (void*)p->dmx, (void*)p->dmy, (void*)p->filt, (void*)p->a, (void*)p->b, (void*)p->c,
-                    (void*)p->padded, (void*)p->amax})
+                    (void*)p->padded, (void*)p->amax, (void*)p->mr_filt, (void*)p->mr_T, (void*)p->mr_amax})
         if (q) (void)hipFree(q);
     for (int l = 0; l < B4D_WIENER_LANES; ++l) {
         b4d_wiener::Lane& L = p->lane[l];
@@ -1173,11 +1195,66 @@ int b4d_wiener_create(int h, int w, const float* psf_host, int ky, int kx, float
         if (hipDeviceSynchronize() != hipSuccess) rc = fail(B4D_EHIP, "wiener filter setup failed");
     }
     (void)hipFree(Hf);
+    if (rc == B4D_OK && wmr_supported(p->H) && wmr_supported(p->W)) {
+        // mixed-radix route: keep the Wh = W/2 + 1 independent filter columns at the workspace pitch, drop the work
+        // buffers of the general route (only the set-up transforms above needed them)
+        WmrGeom& g = p->geom;
+        g.h = h, g.w = w, g.py = p->py, g.px = p->px, g.H = p->H, g.W = p->W;
+        g.Wh = p->W / 2 + 1;
+        g.Hp = (p->H + 1 + 15) / 16 * 16;
+        g.hp = (p->H + 1) / 2;
+        g.clip = 0;
+        g.inv = 1.0f / ((float)p->H * (float)p->W);
+        e = hipMalloc((void**)&p->mr_filt, sizeof(float2) * (size_t)g.Wh * g.Hp);
+        if (e == hipSuccess) e = hipMemset(p->mr_filt, 0, sizeof(float2) * (size_t)g.Wh * g.Hp);
+        if (e == hipSuccess)
+            e = hipMemcpy2D(p->mr_filt, sizeof(float2) * g.Hp, p->filt, sizeof(float2) * p->H, sizeof(float2) * p->H, g.Wh,
+                            hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) rc = fail(B4D_ENOMEM, std::string("wiener filter (mixed-radix route): ") + hipGetErrorString(e));
+        if (rc == B4D_OK) {
+            for (float2** q : {&p->filt, &p->a, &p->b, &p->c}) {
+                (void)hipFree(*q);
+                *q = nullptr;
+            }
+            (void)hipFree(p->padded);
+            p->padded = nullptr;
+            p->mr = true;
+        }
+    }
     if (rc != B4D_OK) {
         b4d_wiener_destroy(p);
         return rc;
     }
     *out = p;
+    return B4D_OK;
+}
+
+// frames [0, batch) through the three kernels of b4d_wiener_mr.hip, B4D_WIENER_FPL frames per launch, all on `st`
+static int wiener_mr_apply(b4d_wiener* p, const float* frames, int batch, float* out, int clip, hipStream_t st) {
+    WmrGeom g = p->geom;
+    g.clip = clip;
+    const int fpl = std::min(batch, wiener_fpl());
+    if (fpl > p->mr_cap) {   // work queued earlier on other streams may still use the old buffers: drain before freeing
+        B4D_HIP(hipDeviceSynchronize());
+        for (void* q : {(void*)p->mr_T, (void*)p->mr_amax})
+            if (q) (void)hipFree(q);
+        p->mr_T = nullptr;
+        p->mr_amax = nullptr;
+        p->mr_cap = 0;
+        hipError_t e = hipMalloc((void**)&p->mr_T, sizeof(float2) * (size_t)fpl * g.Wh * g.Hp);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->mr_amax, sizeof(float) * (size_t)fpl * (g.hp + 1));
+        if (e != hipSuccess) return fail(B4D_ENOMEM, std::string("wiener workspace: ") + hipGetErrorString(e));
+        p->mr_cap = fpl;
+    }
+    const size_t fp = (size_t)g.h * g.w;
+    for (int b0 = 0; b0 < batch; b0 += fpl) {
+        const int nf = std::min(fpl, batch - b0);
+        int rc;
+        float* pmax = p->mr_amax + p->mr_cap;
+        if ((rc = wmr_rows_fwd(frames + b0 * fp, p->mr_T, p->twx, pmax, g, nf, st))) return rc;
+        if ((rc = wmr_cols(p->mr_T, p->mr_filt, p->twy, pmax, p->mr_amax, g, nf, st))) return rc;
+        if ((rc = wmr_rows_inv(p->mr_T, out + b0 * fp, p->twx, p->mr_amax, g, nf, st))) return rc;
+    }
     return B4D_OK;
 }
 
@@ -1257,6 +1334,7 @@ int b4d_wiener_apply(b4d_wiener* p, const float* frames, int batch, float* out, 
     if (batch < 1) return fail(B4D_EINVAL, "batch must be >= 1");
     hipStream_t st = (hipStream_t)stream;
     const size_t fp = (size_t)p->h * p->w;
+    if (p->mr) return wiener_mr_apply(p, frames, batch, out, clip, st);
     if (batch == 1) return wiener_frame(p, 0, frames, out, clip, st);
     int rc = wiener_lanes(p);
     if (rc) return rc;

@@ -1,0 +1,382 @@
+// b4d_wiener_mr.hip -- the three-kernel Wiener pipeline of deconvolve_psf (preprocessing/filters.py:233-289,
+// BASELINE.json config 5) for padded sizes whose sides factor into three in-register radices (4104 = 8 * 27 * 19).
+//
+// Per frame (several frames per launch), no padded copy, no transpose passes, no separate max pass:
+//   k_wmr_rows_fwd  a workgroup owns FOUR row pairs (8 padded rows) at a time, one 256-lane group and one LDS row buffer
+//                   per pair: the pair (2 s, 2 s + 1) of the reflect-padded frame is read straight from the (h, w) frame as
+//                   a + i b, ONE complex transform (b4d_mixed.hpp), Hermitian split into the two half rows.  The store is
+//                   the transposition: column k of the half spectrum is a contiguous run T[k][0 .. H), and four
+//                   neighbouring lanes write the four pairs' pieces {Fa[k], Fb[k]} = ONE aligned 64-byte sector.
+//                   (Measured with the B4D_EXP_WMR builds: one pair per workgroup = 16-byte pieces costs the pass
+//                   +25 us per 4k frame, 32-byte pieces +15 us, 64-byte pieces nothing; the L2 takes a partial-sector
+//                   write as slowly as a whole one.)  max|rows of the pair| (np.nanmax(np.abs(padded)), filters.py:255)
+//                   rides along, one value per pair -- 8 k same-address atomics per frame cost 50 us.
+//   k_wmr_cols      one spectrum column per workgroup, resident in LDS: forward transform, times the transposed Wiener
+//                   filter W[k][ky], inverse transform, back in place (the column never leaves the CU in between).
+//                   Column 0 of every frame also reduces the pair maxima to max|frame|.
+//   k_wmr_rows_inv  four pairs per workgroup again: 64-byte pieces gathered by four neighbouring lanes, Hermitian-extended
+//                   to Ga + i Gb in LDS, ONE inverse transform per pair, real part -> row 2 s, imaginary part -> row
+//                   2 s + 1; 1/(H W), the reference's normalise / clip / rescale (filters.py:259-266, 287-289) and the
+//                   crop folded into the store.
+// The row kernels keep 140 KB of LDS (4 x 34 KB row buffers), i.e. one 1024-lane workgroup per CU: they are persistent
+// (grid = CUs, a loop over quads) and issue the next quad's frame loads before the current quad's store loop.
+// The reference divides the padded frame by max|.| BEFORE the (linear) filter and multiplies back after the clip; here
+// the division is applied to the filtered value just before the clip -- the same real-number result, different by one
+// float32 rounding of the scale (the maximum is only known after the first pass over the frame).
+// HBM/MALL traffic per frame at 4096^2, sigma 1.5: frame in 67 MB + spectrum out 67 + column in/out 135 + filter 67 +
+// spectrum in 67 + frame out 67 = 470 MB (the route it replaces moved 938 MB in 9 kernels).
+#include "b4d_common.hpp"
+#include "b4d_mixed.hpp"
+#include "b4d_wiener_mr.hpp"
+
+namespace b4d {
+
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+constexpr int WMR_Q = 4;   // row pairs per workgroup of the row kernels: 4 x 16-byte pieces = one 64-byte sector
+
+template <class MX>
+__host__ __device__ constexpr size_t wmr_rows_lds() {
+    return sizeof(float2) * ((size_t)WMR_Q * MX::BUF + MX::M1) + sizeof(float) * (WMR_Q * MX::LANES / 64);
+}
+
+// quad q (over all frames of the launch) -> frame f, first pair 4 qi of the frame
+struct QuadRef {
+    int f, qi;
+};
+
+template <class MX>
+__global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* __restrict__ frames, float2* __restrict__ T,
+                                                                    const float2* __restrict__ twN, float* __restrict__ pmax, WmrGeom g,
+                                                                    int nquads, int qpf) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr int R1 = MX::R1, M1 = MX::M1, L = MX::LANES, RD = MX::ROUNDS1, N = MX::N, WG = WMR_Q * L;
+    const int tid = threadIdx.x, lt = tid % L;
+    float2* tw2 = sm + (size_t)WMR_Q * MX::BUF;
+    float* wmax = reinterpret_cast<float*>(tw2 + M1);   // [sub][wave of the group]
+    for (int t = tid; t < M1; t += WG) tw2[t] = twN[R1 * t];
+
+    float2 v[RD][R1];
+    float mx = 0.f;
+    // frame loads of quad q for this lane's pair (compute mapping: lane lt of group sub owns items lt, lt + L, ...)
+    auto load = [&](int q, int lt, int sub) {
+        const int f = q / qpf, pr = WMR_Q * (q - f * qpf) + sub;
+        const bool act = pr < g.hp;
+        const int r0 = 2 * (act ? pr : 0);
+        const bool has_b = act && r0 + 1 < g.H;
+        const int y0 = reflect_idx(r0 - g.py, g.h), y1 = reflect_idx((has_b ? r0 + 1 : r0) - g.py, g.h);
+        const float* fa = frames + ((size_t)f * g.h + y0) * g.w;
+        const float* fb = frames + ((size_t)f * g.h + y1) * g.w;
+        mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+            const int mc = min(lt + r * L, M1 - 1);   // clamped: the loads are unconditional, the item is masked later
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const int x = reflect_idx(M1 * n1 + mc - g.px, g.w);
+                const float a = fa[x], b = fb[x];   // unconditional (fb = fa's row when the pair has no second row)
+                v[r][n1] = make_float2(a, b);
+                mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));   // fmaxf drops NaN operands: np.nanmax
+            }
+        }
+        if (!has_b) {   // wave-uniform: a select per load would put every load under its own branch
+#pragma unroll
+            for (int r = 0; r < RD; ++r)
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) v[r][n1].y = 0.f;
+        }
+    };
+    for (int q = blockIdx.x; q < nquads; q += gridDim.x) {
+        // Everything derived from the lane index or the tables is invariant in q: left alone, the compiler precomputes all of
+        // it (twiddle loads included) ahead of the quad loop and spills > 100 dwords around the radix stages.  Opaque
+        // per-iteration copies keep those values short-lived.
+        int ltq = lt, tidq = tid;
+        const float2* twq = twN;
+        asm volatile("" : "+v"(ltq), "+v"(tidq), "+s"(twq));
+        const int subq = tidq / L;
+        float2* bufq = sm + (size_t)subq * MX::BUF;
+        const float2* tw2q = sm + (size_t)WMR_Q * MX::BUF;
+        const int f = q / qpf, qi = q - f * qpf, pr = WMR_Q * qi + subq;
+        const bool act = pr < g.hp;
+        load(q, ltq, subq);
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+            const int m = ltq + r * L;
+            if (m < M1) MX::stage1_item(v[r], m, bufq, twq);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        if ((tidq & 63) == 0) wmax[tidq >> 6] = mx;
+        __syncthreads();
+        if (ltq == 0 && act) {
+            float m2 = wmax[subq * (L / 64)];
+#pragma unroll
+            for (int i = 1; i < L / 64; ++i) m2 = fmaxf(m2, wmax[subq * (L / 64) + i]);
+            pmax[(size_t)f * g.hp + pr] = m2;
+        }
+        MX::stage2(bufq, tw2q, ltq);
+        __syncthreads();
+        MX::stage3(bufq, ltq);
+        __syncthreads();
+        // piece mapping: lanes 4 i .. 4 i + 3 hold the four pairs' pieces of ONE k: 64 contiguous bytes of T[k][.]
+        const int j = tidq & (WMR_Q - 1), kk = tidq / WMR_Q;
+        const float2* bj = sm + (size_t)j * MX::BUF;
+        const bool wr = WMR_Q * qi + j < g.hp;
+        float2* dst = T + (size_t)f * g.Wh * g.Hp + 2 * (WMR_Q * qi + j);
+        typename MX::template PosIter<L> pk(kk), pn(kk == 0 ? 0 : N - kk);   // k upwards, N - k downwards
+        for (int k = kk; k < g.Wh; k += L) {
+            const float2 z = bj[pk.pos()], w = bj[pn.pos()];
+            if (wr)
+                *reinterpret_cast<float4*>(dst + (size_t)k * g.Hp) =
+                    make_float4(0.5f * (z.x + w.x), 0.5f * (z.y - w.y), 0.5f * (z.y + w.y), 0.5f * (w.x - z.x));
+            pk.up();
+            if (k == 0) pn = typename MX::template PosIter<L>(N - L); else pn.down();
+        }
+        __syncthreads();   // the row buffers are free for the next quad
+    }
+}
+
+template <class MY>
+__global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ T, const float2* __restrict__ filt,
+                                                            const float2* __restrict__ twN, const float* __restrict__ pmax,
+                                                            float* __restrict__ amax, WmrGeom g) {
+    __shared__ __attribute__((aligned(16))) float2 buf[MY::BUF];
+    __shared__ float2 tw2[MY::M1];
+    constexpr int R1 = MY::R1, M1 = MY::M1, LANES = MY::LANES, RD = MY::ROUNDS1, N = MY::N;
+    const int tid = threadIdx.x;
+    const int col = blockIdx.x;
+    const int f = col / g.Wh, k = col - f * g.Wh;
+    float2* x = T + (size_t)col * g.Hp;
+    const float2* fl = filt + (size_t)k * g.Hp;
+    MY::build_tw2(tw2, twN, tid);
+    if (k == 0 && tid < 64) {   // max|frame| from the pair maxima of k_wmr_rows_fwd (fmaxf drops NaN: np.nanmax)
+        float mx = 0.f;
+        for (int i = tid; i < g.hp; i += 64) mx = fmaxf(mx, pmax[(size_t)f * g.hp + i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        if (tid == 0) amax[f] = mx;
+    }
+    float2 v[RD][R1];
+#pragma unroll
+    for (int r = 0; r < RD; ++r) {
+        const int mc = min(tid + r * LANES, M1 - 1);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[r][n1] = x[M1 * n1 + mc];
+    }
+#pragma unroll
+    for (int r = 0; r < RD; ++r) {
+        const int m = tid + r * LANES;
+        if (m < M1) MY::stage1_item(v[r], m, buf, twN);
+    }
+    // the filter values of the second transform's inputs: in flight under the first transform
+    float2 fv[RD][R1];
+#pragma unroll
+    for (int r = 0; r < RD; ++r) {
+        const int mc = min(tid + r * LANES, M1 - 1);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) fv[r][n1] = fl[M1 * n1 + mc];
+    }
+    __syncthreads();
+    MY::stage2(buf, tw2, tid);
+    __syncthreads();
+    MY::stage3(buf, tid);
+    __syncthreads();
+    // inverse = conj(forward(conj(.))): inputs conj(X[n] W[n]) gathered from where the forward transform left X[n]
+#pragma unroll
+    for (int r = 0; r < RD; ++r) {
+        const int mc = min(tid + r * LANES, M1 - 1);
+        typename MY::template PosIter<M1> pi(mc);   // n = mc, mc + M1, ...
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const float2 p = cmul(buf[pi.pos()], fv[r][n1]);
+            v[r][n1] = make_float2(p.x, -p.y);
+            pi.up();
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RD; ++r) {
+        const int m = tid + r * LANES;
+        if (m < M1) MY::stage1_item(v[r], m, buf, twN);
+    }
+    __syncthreads();
+    MY::stage2(buf, tw2, tid);
+    __syncthreads();
+    MY::stage3(buf, tid);
+    __syncthreads();
+    typename MY::template PosIter<LANES> pk(tid);
+    for (int n = tid; n < N; n += LANES) {
+        const float2 z = buf[pk.pos()];
+        x[n] = make_float2(z.x, -z.y);
+        pk.up();
+    }
+}
+
+template <class MX>
+__global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_inv(const float2* __restrict__ T, float* __restrict__ out,
+                                                                    const float2* __restrict__ twN, const float* __restrict__ amax, WmrGeom g,
+                                                                    int nquads, int qpf) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr int R1 = MX::R1, M1 = MX::M1, L = MX::LANES, RD = MX::ROUNDS1, N = MX::N, WG = WMR_Q * L;
+    const int tid = threadIdx.x, lt = tid % L;
+    float2* tw2 = sm + (size_t)WMR_Q * MX::BUF;
+    for (int t = tid; t < M1; t += WG) tw2[t] = twN[R1 * t];
+    for (int q = blockIdx.x; q < nquads; q += gridDim.x) {
+        int ltq = lt, tidq = tid;   // opaque per-iteration copies (see k_wmr_rows_fwd)
+        const float2* twq = twN;
+        asm volatile("" : "+v"(ltq), "+v"(tidq), "+s"(twq));
+        const int subq = tidq / L;
+        float2* bufq = sm + (size_t)subq * MX::BUF;
+        const float2* tw2q = sm + (size_t)WMR_Q * MX::BUF;
+        const int f = q / qpf, qi = q - f * qpf, pr = WMR_Q * qi + subq;
+        {   // piece mapping: four neighbouring lanes gather the four pairs' 16-byte pieces of ONE k (a 64-byte sector);
+            // Ga + i Gb, Hermitian-extended beyond N/2, conjugated for the inverse, lands in natural order in the pair's buffer
+            const int j = tidq & (WMR_Q - 1), kk = tidq / WMR_Q, pj = WMR_Q * qi + j;
+            float2* bj = sm + (size_t)j * MX::BUF;
+            const bool rd = pj < g.hp, hb = 2 * pj + 1 < g.H;
+            const float2* src = T + (size_t)f * g.Wh * g.Hp + 2 * (rd ? pj : 0);
+            for (int k = kk; k < g.Wh; k += L) {
+                const float4 p = *reinterpret_cast<const float4*>(src + (size_t)k * g.Hp);
+                const float bx = hb ? p.z : 0.f, by = hb ? p.w : 0.f;
+                bj[k] = make_float2(p.x - by, -(p.y + bx));
+                if (k != 0 && 2 * k != N) bj[N - k] = make_float2(p.x + by, p.y - bx);
+            }
+        }
+        __syncthreads();
+        float2 v[RD][R1];
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+            const int mc = min(ltq + r * L, M1 - 1);
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) v[r][n1] = bufq[M1 * n1 + mc];
+        }
+        __syncthreads();   // every input is in registers: stage 1 may overwrite the buffer
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+            const int m = ltq + r * L;
+            if (m < M1) MX::stage1_item(v[r], m, bufq, twq);
+        }
+        __syncthreads();
+        MX::stage2(bufq, tw2q, ltq);
+        __syncthreads();
+        MX::stage3(bufq, ltq);
+        __syncthreads();
+        // np: work = padded / scale; restored = clip(wiener(work)) * scale (filters.py:259-266, 287): the 1/(H W) of the
+        // inverse transform and the division by the scale are one factor here
+        const float fsc = amax[f];
+        const bool fok = isfinite(fsc) && fsc != 0.f;
+        const float sc = g.inv / fsc;
+        const int r0 = 2 * pr, ya = r0 - g.py, yb = ya + 1;
+        const bool act = pr < g.hp;
+        const bool wa = act && ya >= 0 && ya < g.h, wb = act && r0 + 1 < g.H && yb >= 0 && yb < g.h;
+        float* orow = out + ((size_t)f * g.h + ya) * g.w;
+        typename MX::template PosIter<L> pk(ltq + g.px);
+        for (int x = ltq; x < g.w; x += L) {
+            const float2 z = bufq[pk.pos()];
+            pk.up();
+            float va = z.x * sc, vb = -z.y * sc;   // conj(buf): real part row a, imaginary part row b
+            if (g.clip) {                          // np.clip: NaN stays NaN
+                va = (va > 1.f ? 1.f : (va < -1.f ? -1.f : va));
+                vb = (vb > 1.f ? 1.f : (vb < -1.f ? -1.f : vb));
+            }
+            if (wa) orow[x] = fok ? va * fsc : 0.f;
+            if (wb) orow[g.w + x] = fok ? vb * fsc : 0.f;
+        }
+        __syncthreads();   // the row buffers are free for the next quad
+    }
+}
+
+// ---- instantiated lengths -----------------------------------------------------------------------------------------
+//   4104 = 4096 + 8 (sigma 1.5 on 4k frames), 520 = 512 + 8, 264 = 256 + 8
+#define B4D_WMR_LENGTHS(X)       \
+    X(4104, 8, 27, 19, 256)      \
+    X(520, 8, 5, 13, 128)        \
+    X(264, 8, 3, 11, 64)
+
+bool wmr_supported(int n) {
+#define X(N_, A_, B_, C_, L_) \
+    if (n == N_) return true;
+    B4D_WMR_LENGTHS(X)
+#undef X
+    return false;
+}
+
+static int wmr_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
+// persistent row kernels: one workgroup per CU when a workgroup needs most of the LDS, as many as fit otherwise
+template <class MX, class K>
+static int wmr_rows_launch(K kernel, int nquads, hipStream_t st, size_t* lds_out, int* grid_out) {
+    const size_t lds = wmr_rows_lds<MX>();
+    static std::once_flag once;
+    static hipError_t attr = hipSuccess;
+    std::call_once(once, [&] { attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    B4D_HIP(attr);
+    const int per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / lds), 2048 / (WMR_Q * MX::LANES)));
+    *lds_out = lds;
+    *grid_out = std::min(nquads, wmr_cus() * per_cu);
+    return B4D_OK;
+}
+
+int wmr_rows_fwd(const float* frames, float2* T, const float2* twx, float* pmax, const WmrGeom& g, int nframes, hipStream_t st) {
+    const int qpf = (g.hp + WMR_Q - 1) / WMR_Q, nquads = nframes * qpf;
+    size_t lds = 0;
+    int grid = 0, rc;
+    switch (g.W) {
+#define X(N_, A_, B_, C_, L_)                                                                                                              \
+    case N_: {                                                                                                                             \
+        using MX = Mix3<A_, B_, C_, L_>;                                                                                                   \
+        if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_fwd<MX>, nquads, st, &lds, &grid))) return rc;                                          \
+        hipLaunchKernelGGL((k_wmr_rows_fwd<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, frames, T, twx, pmax, g, nquads, qpf);              \
+    } break;
+        B4D_WMR_LENGTHS(X)
+#undef X
+        default: return fail(B4D_ESIZE, "no mixed-radix row kernel for this length");
+    }
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int wmr_cols(float2* T, const float2* filt, const float2* twy, const float* pmax, float* amax, const WmrGeom& g, int nframes,
+             hipStream_t st) {
+    const unsigned grid = (unsigned)nframes * (unsigned)g.Wh;
+    switch (g.H) {
+#define X(N_, A_, B_, C_, L_)                                                                                                  \
+    case N_:                                                                                                                   \
+        hipLaunchKernelGGL((k_wmr_cols<Mix3<A_, B_, C_, L_>>), dim3(grid), dim3(L_), 0, st, T, filt, twy, pmax, amax, g);      \
+        break;
+        B4D_WMR_LENGTHS(X)
+#undef X
+        default: return fail(B4D_ESIZE, "no mixed-radix column kernel for this length");
+    }
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int wmr_rows_inv(const float2* T, float* out, const float2* twx, const float* amax, const WmrGeom& g, int nframes, hipStream_t st) {
+    const int qpf = (g.hp + WMR_Q - 1) / WMR_Q, nquads = nframes * qpf;
+    size_t lds = 0;
+    int grid = 0, rc;
+    switch (g.W) {
+#define X(N_, A_, B_, C_, L_)                                                                                                              \
+    case N_: {                                                                                                                             \
+        using MX = Mix3<A_, B_, C_, L_>;                                                                                                   \
+        if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_inv<MX>, nquads, st, &lds, &grid))) return rc;                                          \
+        hipLaunchKernelGGL((k_wmr_rows_inv<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, T, out, twx, amax, g, nquads, qpf);                 \
+    } break;
+        B4D_WMR_LENGTHS(X)
+#undef X
+        default: return fail(B4D_ESIZE, "no mixed-radix row kernel for this length");
+    }
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+}  // namespace b4d

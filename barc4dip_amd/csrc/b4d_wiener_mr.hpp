@@ -1,0 +1,28 @@
+// b4d_wiener_mr.hpp -- interface of the mixed-radix Wiener kernels (b4d_wiener_mr.hip) used by b4d_wiener.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace b4d {
+
+struct WmrGeom {
+    int h, w, py, px;   // frame and half kernel
+    int H, W;           // padded size
+    int Wh;             // W / 2 + 1 independent spectrum columns
+    int Hp;             // pitch (complex words) of one column in the transposed workspace, a multiple of 16, > H if H is odd
+    int hp;             // row pairs per frame, (H + 1) / 2
+    int clip;
+    float inv;          // 1 / (H W)
+};
+
+// the length has a compiled three-radix kernel
+bool wmr_supported(int n);
+// frames (nframes, h, w) -> T (nframes, Wh, Hp) transposed half spectra; pmax (nframes, hp) = max|rows of each pair|
+int wmr_rows_fwd(const float* frames, float2* T, const float2* twx, float* pmax, const WmrGeom& g, int nframes, hipStream_t st);
+// every column of T: forward transform, times filt (Wh, Hp), inverse transform (unscaled), in place;
+// amax[f] = max|frame f| reduced from pmax
+int wmr_cols(float2* T, const float2* filt, const float2* twy, const float* pmax, float* amax, const WmrGeom& g, int nframes,
+             hipStream_t st);
+// T -> out (nframes, h, w): inverse row transforms, 1/(H W), normalise by max|frame|, clip, rescale, crop
+int wmr_rows_inv(const float2* T, float* out, const float2* twx, const float* amax, const WmrGeom& g, int nframes, hipStream_t st);
+
+}  // namespace b4d

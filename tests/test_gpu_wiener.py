@@ -19,7 +19,10 @@ def pp():
 
 
 @pytest.mark.parametrize("shape,sigma", [((60, 52), 1.5), ((64, 64), (1.0, 2.0)), ((100, 37), 0.7), ((512, 512), 1.5),
-                                         ((70, 258), 0.7), ((258, 258), 0.7)])  # 262 = 2 * 131: DFT-matrix fallback
+                                         ((70, 258), 0.7), ((258, 258), 0.7),   # 262 = 2 * 131: DFT-matrix fallback
+                                         # padded 264 = 8*3*11 / 520 = 8*5*13: the three-kernel mixed-radix route
+                                         # (b4d_wiener_mr.hip) on square and both non-square orientations
+                                         ((256, 256), 1.5), ((256, 512), 1.5), ((512, 256), 1.5)])
 @pytest.mark.parametrize("clip", [True, False])
 def test_wiener_vs_oracle(pp, shape, sigma, clip):
     from oracle import wiener_np as W
@@ -29,6 +32,46 @@ def test_wiener_vs_oracle(pp, shape, sigma, clip):
     ref = W.deconvolve_psf(img, sigma=sigma, clip=clip)
     assert got.shape == img.shape and got.dtype == np.float32
     assert float(np.max(np.abs(got - ref))) < 2e-5 * float(np.max(np.abs(img)))
+
+
+@pytest.mark.parametrize("clip", [True, False])
+def test_cfg5_size(pp, clip):
+    """BASELINE.json config 5 at its stated size: one 4096 x 4096 frame, sigma 1.5 (9 x 9 PSF, padded 4104 = 8 * 27 * 19),
+    preprocessing/filters.py:233-289.  2e-5 of the data range against the float32 oracle (parity unpinned: scikit-image).
+    The clip matters here: the Wiener filter overshoots the normalised range at the brightest grains."""
+    import torch
+    from oracle import wiener_np as W
+
+    img = synth.speckle_frame(4096, 77)
+    ref = W.deconvolve_psf(img, sigma=1.5, clip=clip)
+    got = pp.deconvolve_psf(img, sigma=1.5, clip=clip)
+    assert got.shape == img.shape and got.dtype == np.float32
+    err = float(np.max(np.abs(got - ref))) / float(np.max(np.abs(img)))
+    print(f"cfg5 4096^2 clip={clip}: max err / range = {err:.2e}")
+    assert err < 2e-5
+    if clip:   # says whether the clip is active on this frame (then max|restored| is exactly the frame maximum)
+        print("clip active:", float(np.max(np.abs(ref))) == float(np.max(np.abs(img))))
+    # a multi-frame call (several frames per launch) reproduces the single-frame result bit for bit
+    dev = torch.from_numpy(np.stack([img, img[::-1].copy(), img[:, ::-1].copy()])).cuda()
+    out = pp.deconvolve_psf(dev, sigma=1.5, clip=clip, return_tensors=True)
+    assert np.array_equal(out[0].cpu().numpy(), got)
+    assert np.array_equal(out[1].cpu().numpy(), pp.deconvolve_psf(img[::-1].copy(), sigma=1.5, clip=clip))
+
+
+def test_mixed_radix_route_special_values(pp):
+    """np.nanmax / np.clip semantics on the mixed-radix route (padded 264): NaN pixel -> NaN frame, all-zero and
+    infinite-maximum frames -> zeros (filters.py:255-257), an odd number of frames per call."""
+    from oracle import wiener_np as W
+
+    stack = synth.speckle_stack(5, 256, seed0=90)
+    stack[1, 10, 20] = np.nan
+    stack[2] = 0.0
+    stack[3, 100, 7] = np.inf
+    got = pp.deconvolve_psf(stack, sigma=1.5)
+    assert np.isnan(got[1]).all() and np.all(got[2] == 0) and np.all(got[3] == 0)
+    for t in (0, 4):
+        ref = W.deconvolve_psf(stack[t], sigma=1.5)
+        assert float(np.max(np.abs(got[t] - ref))) < 2e-5 * float(stack[t].max())
 
 
 def test_stack_balance_and_errors(pp):
