@@ -67,7 +67,7 @@ struct Mix3 {
     static __device__ __forceinline__ void stage1_item(float2 (&v)[R1], int m, float2* __restrict__ buf, const float2* __restrict__ twN) {
         float2 w[R1];
 #pragma unroll
-        for (int k1 = 1; k1 < R1; ++k1) w[k1] = twN[m * k1];
+        for (int k1 = 1; k1 < R1; ++k1) w[k1] = twN[__umul24(m, k1)];   // v_mul_u32_u24 is full rate, v_mul_lo_u32 a quarter
         Radix<R1>::run(v);
         buf[m] = v[0];
 #pragma unroll
@@ -82,8 +82,15 @@ struct Mix3 {
             for (int n2 = 0; n2 < R2; ++n2) v[n2] = p[R3 * n2];
             Radix<R2>::run(v);
             p[0] = v[0];
+            // tw2[n3 k2] through a running index: left to itself the compiler turns the additions back into one quarter-rate
+            // 32-bit multiply per twiddle (and recomputes it rather than keep it in a register)
+            int ti = 0;
 #pragma unroll
-            for (int k2 = 1; k2 < R2; ++k2) p[R3 * k2] = cmul(v[k2], tw2[n3 * k2]);
+            for (int k2 = 1; k2 < R2; ++k2) {
+                ti += n3;
+                asm volatile("" : "+v"(ti));
+                p[R3 * k2] = cmul(v[k2], tw2[ti]);
+            }
         }
     }
     static __device__ __forceinline__ void stage3(float2* __restrict__ buf, int tid) {

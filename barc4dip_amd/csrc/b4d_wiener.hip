@@ -796,10 +796,11 @@ struct b4d_wiener {
     int mr_cap = 0;
 };
 
-// frames per launch of the mixed-radix route: enough rows to hide the ragged tail of a launch (2052 pairs on 1024
-// resident workgroups), few enough that the spectra of a launch (67 MB per 4k frame) stay in the 256-MiB infinity cache
+// frames per launch of the mixed-radix route: the persistent row kernels hand 513 quads per 4k frame to 256 workgroups
+// (2.004 rounds), so a launch needs several frames to amortise its last, nearly empty round (measured on MI355X,
+// 4096^2: 1 frame per launch 5.6 k frames/s, 4: 6.8 k, 8: 7.15 k, 16: 7.2 k); 68 MB of workspace per frame
 #ifndef B4D_WIENER_FPL
-#define B4D_WIENER_FPL 2
+#define B4D_WIENER_FPL 8
 #endif
 static int wiener_fpl() {
     static const int v = [] {

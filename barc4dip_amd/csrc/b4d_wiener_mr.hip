@@ -86,6 +86,10 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
                 for (int n1 = 0; n1 < R1; ++n1) v[r][n1].y = 0.f;
         }
     };
+#ifndef B4D_WMR_PREFETCH
+#define B4D_WMR_PREFETCH 1   // issue the next quad's global loads before the current quad's store loop (A/B: tools/dev_cfg5.py)
+#endif
+    if (B4D_WMR_PREFETCH && (int)blockIdx.x < nquads) load(blockIdx.x, (lt + 64 * (tid / L)) % L, tid / L);
     for (int q = blockIdx.x; q < nquads; q += gridDim.x) {
         // Everything derived from the lane index or the tables is invariant in q: left alone, the compiler precomputes all of
         // it (twiddle loads included) ahead of the quad loop and spills > 100 dwords around the radix stages.  Opaque
@@ -98,10 +102,14 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
         const float2* tw2q = sm + (size_t)WMR_Q * MX::BUF;
         const int f = q / qpf, qi = q - f * qpf, pr = WMR_Q * qi + subq;
         const bool act = pr < g.hp;
-        load(q, ltq, subq);
+        // The stages have M1 / M2 / M3 items for L lanes, so each leaves the group's last waves idle (radix 27: 152 items,
+        // waves 2.4 .. 3).  Wave w of every group sits on SIMD w % 4: rotating the item <-> lane map by one wave per
+        // group spreads the idle waves over the four SIMDs instead of parking all of them on SIMD 3.
+        const int ltr = (ltq + 64 * subq) % L;
+        if (!B4D_WMR_PREFETCH) load(q, ltr, subq);
 #pragma unroll
         for (int r = 0; r < RD; ++r) {
-            const int m = ltq + r * L;
+            const int m = ltr + r * L;
             if (m < M1) MX::stage1_item(v[r], m, bufq, twq);
         }
 #pragma unroll
@@ -114,10 +122,11 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
             for (int i = 1; i < L / 64; ++i) m2 = fmaxf(m2, wmax[subq * (L / 64) + i]);
             pmax[(size_t)f * g.hp + pr] = m2;
         }
-        MX::stage2(bufq, tw2q, ltq);
+        MX::stage2(bufq, tw2q, ltr);
         __syncthreads();
-        MX::stage3(bufq, ltq);
+        MX::stage3(bufq, ltr);
         __syncthreads();
+        if (B4D_WMR_PREFETCH && q + (int)gridDim.x < nquads) load(q + gridDim.x, ltr, subq);   // in flight under the store loop
         // piece mapping: lanes 4 i .. 4 i + 3 hold the four pairs' pieces of ONE k: 64 contiguous bytes of T[k][.]
         const int j = tidq & (WMR_Q - 1), kk = tidq / WMR_Q;
         const float2* bj = sm + (size_t)j * MX::BUF;
@@ -221,6 +230,16 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_inv(const float2*
     const int tid = threadIdx.x, lt = tid % L;
     float2* tw2 = sm + (size_t)WMR_Q * MX::BUF;
     for (int t = tid; t < M1; t += WG) tw2[t] = twN[R1 * t];
+    // the 16-byte pieces of quad q this lane gathers (piece mapping: k = tid / 4 + i L, pair tid % 4), clamped addresses
+    constexpr int NP = (N / 2 + 1 + L - 1) / L;
+    float4 pc[NP];
+    auto fetch = [&](int q, int tidq) {
+        const int f = q / qpf, pj = WMR_Q * (q - f * qpf) + (tidq & (WMR_Q - 1)), kk = tidq / WMR_Q;
+        const float2* src = T + (size_t)f * g.Wh * g.Hp + 2 * min(pj, g.hp - 1);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pc[i] = *reinterpret_cast<const float4*>(src + (size_t)min(kk + i * L, g.Wh - 1) * g.Hp);
+    };
+    if (B4D_WMR_PREFETCH && (int)blockIdx.x < nquads) fetch(blockIdx.x, tid);
     for (int q = blockIdx.x; q < nquads; q += gridDim.x) {
         int ltq = lt, tidq = tid;   // opaque per-iteration copies (see k_wmr_rows_fwd)
         const float2* twq = twN;
@@ -233,33 +252,38 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_inv(const float2*
             // Ga + i Gb, Hermitian-extended beyond N/2, conjugated for the inverse, lands in natural order in the pair's buffer
             const int j = tidq & (WMR_Q - 1), kk = tidq / WMR_Q, pj = WMR_Q * qi + j;
             float2* bj = sm + (size_t)j * MX::BUF;
-            const bool rd = pj < g.hp, hb = 2 * pj + 1 < g.H;
-            const float2* src = T + (size_t)f * g.Wh * g.Hp + 2 * (rd ? pj : 0);
-            for (int k = kk; k < g.Wh; k += L) {
-                const float4 p = *reinterpret_cast<const float4*>(src + (size_t)k * g.Hp);
-                const float bx = hb ? p.z : 0.f, by = hb ? p.w : 0.f;
-                bj[k] = make_float2(p.x - by, -(p.y + bx));
-                if (k != 0 && 2 * k != N) bj[N - k] = make_float2(p.x + by, p.y - bx);
+            const bool hb = 2 * pj + 1 < g.H;
+            if (!B4D_WMR_PREFETCH) fetch(q, tidq);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int k = kk + i * L;
+                if (k < g.Wh) {
+                    const float4 p = pc[i];
+                    const float bx = hb ? p.z : 0.f, by = hb ? p.w : 0.f;
+                    bj[k] = make_float2(p.x - by, -(p.y + bx));
+                    if (k != 0 && 2 * k != N) bj[N - k] = make_float2(p.x + by, p.y - bx);
+                }
             }
         }
         __syncthreads();
+        const int ltr = (ltq + 64 * subq) % L;   // item <-> lane map rotated by one wave per group (see k_wmr_rows_fwd)
         float2 v[RD][R1];
 #pragma unroll
         for (int r = 0; r < RD; ++r) {
-            const int mc = min(ltq + r * L, M1 - 1);
+            const int mc = min(ltr + r * L, M1 - 1);
 #pragma unroll
             for (int n1 = 0; n1 < R1; ++n1) v[r][n1] = bufq[M1 * n1 + mc];
         }
         __syncthreads();   // every input is in registers: stage 1 may overwrite the buffer
 #pragma unroll
         for (int r = 0; r < RD; ++r) {
-            const int m = ltq + r * L;
+            const int m = ltr + r * L;
             if (m < M1) MX::stage1_item(v[r], m, bufq, twq);
         }
         __syncthreads();
-        MX::stage2(bufq, tw2q, ltq);
+        MX::stage2(bufq, tw2q, ltr);
         __syncthreads();
-        MX::stage3(bufq, ltq);
+        MX::stage3(bufq, ltr);
         __syncthreads();
         // np: work = padded / scale; restored = clip(wiener(work)) * scale (filters.py:259-266, 287): the 1/(H W) of the
         // inverse transform and the division by the scale are one factor here
@@ -270,6 +294,7 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_inv(const float2*
         const bool act = pr < g.hp;
         const bool wa = act && ya >= 0 && ya < g.h, wb = act && r0 + 1 < g.H && yb >= 0 && yb < g.h;
         float* orow = out + ((size_t)f * g.h + ya) * g.w;
+        if (B4D_WMR_PREFETCH && q + (int)gridDim.x < nquads) fetch(q + gridDim.x, tidq);   // in flight under the store loop
         typename MX::template PosIter<L> pk(ltq + g.px);
         for (int x = ltq; x < g.w; x += L) {
             const float2 z = bufq[pk.pos()];

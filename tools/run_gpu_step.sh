@@ -1,7 +1,7 @@
-mkdir -p gpurun_out/r2f
-timeout -k 10 900 python -m pytest tests/test_gpu_wiener.py tests/test_gpu_prep.py tests/test_gpu_signal.py -x -q -m gpu > gpurun_out/r2f/pytest.log 2>&1; tail -3 gpurun_out/r2f/pytest.log
-for f in 1 4 8; do
-B4D_WIENER_FPL=$f bash tools/prof_stats.sh r2f/base$f tools/dev_cfg5.py - 32 > /dev/null
-echo "== base FPL $f"; python3 tools/prof_summary.py gpurun_out/r2f/base$f | head -3; tail -1 gpurun_out/r2f/base$f.log
+mkdir -p gpurun_out/r2g
+timeout -k 10 900 python -m pytest tests/test_gpu_wiener.py -x -q -m gpu > gpurun_out/r2g/pytest.log 2>&1; tail -3 gpurun_out/r2g/pytest.log
+for lib in - $GRAFT_REPO_ROOT/barc4dip_amd/csrc/libb4d_nopf.so; do
+B4D_WIENER_FPL=8 bash tools/prof_stats.sh r2g/p tools/dev_cfg5.py $lib 32 > /dev/null
+echo "== $lib FPL 8"; python3 tools/prof_summary.py gpurun_out/r2g/p | head -3
+for f in 4 8 16; do B4D_WIENER_FPL=$f python tools/dev_cfg5.py $lib 32 2>&1 | tail -1; done
 done
-for f in 1 2 4 8 16; do B4D_WIENER_FPL=$f python tools/dev_cfg5.py - 32 2>&1 | tail -1; done
