@@ -55,6 +55,8 @@ SIGNATURES = {
     "b4d_template_match": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
     "b4d_temporal_accumulate": (_i, [_vp, _i, _sz, _vp, _vp, _vp]),
     "b4d_temporal_finalize": (_i, [_vp, _vp, _d, _sz, _vp, _vp, _vp, _vp]),
+    "b4d_temporal_accumulate_range": (_i, [_vp, _i, _sz, _sz, _sz, _vp, _vp, _vp]),
+    "b4d_temporal_finalize_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "b4d_moments": (_i, [_vp, _i, _sz, _d, _d, _vp, _vp]),
     "b4d_sobel_laplace_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "b4d_stack_mean_f32": (_i, [_vp, _i, _sz, _vp, _vp]),

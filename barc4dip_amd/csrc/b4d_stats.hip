@@ -117,11 +117,70 @@ __global__ void __launch_bounds__(256) k_temporal_acc(const float* __restrict__ 
     }
 }
 
-__global__ void __launch_bounds__(256) k_temporal_fin(const double* __restrict__ sx, const double* __restrict__ sxx,
-                                                      double count, size_t npix, float* __restrict__ mean,
-                                                      float* __restrict__ var, float* __restrict__ contrast) {
+// Any pixel count / alignment (1023 x 1023 frames: odd rows start on odd dwords): one lane per pixel, dword loads
+// (still whole 256-byte lines per wave), four frames in flight.  `stride` = pixels from one frame to the next.
+__global__ void __launch_bounds__(256) k_temporal_acc1(const float* __restrict__ frames, int nframes, size_t stride, size_t npix,
+                                                       double* __restrict__ sx, double* __restrict__ sxx) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
+    const float* p = frames + i;
+    double a = 0, q = 0;
+    int t = 0;
+    for (; t + 4 <= nframes; t += 4) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = p[(size_t)(t + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double x = v[k];
+            a += x;
+            q = fma(x, x, q);
+        }
+    }
+    for (; t < nframes; ++t) {
+        const double x = p[(size_t)t * stride];
+        a += x;
+        q = fma(x, x, q);
+    }
+    sx[i] += a;
+    sxx[i] += q;
+}
+
+// 16-byte variant on a pixel range of strided frames (npix and every frame start a multiple of 4 pixels)
+__global__ void __launch_bounds__(256) k_temporal_acc4(const float* __restrict__ frames, int nframes, size_t stride, size_t npix,
+                                                       double* __restrict__ sx, double* __restrict__ sxx) {
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= npix) return;
+    double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const float* p = frames + i4;
+    auto take = [&](const float4& v) {
+        const double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+        a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3;
+        q[0] = fma(x0, x0, q[0]); q[1] = fma(x1, x1, q[1]); q[2] = fma(x2, x2, q[2]); q[3] = fma(x3, x3, q[3]);
+    };
+    int t = 0;
+    for (; t + 4 <= nframes; t += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(p + (size_t)(t + k) * stride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) take(v[k]);
+    }
+    for (; t < nframes; ++t) take(*reinterpret_cast<const float4*>(p + (size_t)t * stride));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sx[i4 + k] += a[k];
+        sxx[i4 + k] += q[k];
+    }
+}
+
+// count by value (count_dev == nullptr) or from device memory (the all-reduced frame count: no host round trip)
+__global__ void __launch_bounds__(256) k_temporal_fin(const double* __restrict__ sx, const double* __restrict__ sxx,
+                                                      double count_val, const double* __restrict__ count_dev, size_t npix,
+                                                      float* __restrict__ mean, float* __restrict__ var, float* __restrict__ contrast) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const double count = count_dev ? count_dev[0] : count_val;
     const double m = sx[i] / count;
     double v = sxx[i] / count - m * m;
     v = v > 0.0 ? v : 0.0;
@@ -719,11 +778,26 @@ int b4d_temporal_accumulate(const float* frames, int nframes, size_t npix, doubl
                             void* stream) {
     if (!frames || !sum_x || !sum_xx) return fail(B4D_EINVAL, "null argument");
     if (nframes < 1 || npix < 1) return fail(B4D_EINVAL, "nframes and npix must be >= 1");
-    if ((reinterpret_cast<uintptr_t>(frames) & 15) || (npix & 3))
-        return fail(B4D_EINVAL, "frames must be 16-byte aligned and npix a multiple of 4");
-    const size_t lanes = (npix + 3) / 4;
-    hipLaunchKernelGGL(k_temporal_acc, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames,
-                       nframes, npix, sum_x, sum_xx);
+    return b4d_temporal_accumulate_range(frames, nframes, npix, 0, npix, sum_x, sum_xx, stream);
+}
+
+int b4d_temporal_accumulate_range(const float* frames, int nframes, size_t frame_stride, size_t pix0, size_t npix, double* sum_x,
+                                  double* sum_xx, void* stream) {
+    if (!frames || !sum_x || !sum_xx) return fail(B4D_EINVAL, "null argument");
+    if (nframes < 1 || npix < 1 || pix0 + npix > frame_stride) return fail(B4D_EINVAL, "bad frame count or pixel range");
+    const float* f0 = frames + pix0;
+    if ((reinterpret_cast<uintptr_t>(f0) & 15) == 0 && (npix & 3) == 0 && (frame_stride & 3) == 0) {
+        if (pix0 == 0 && npix == frame_stride) {   // whole contiguous frames: the original kernel (ragged tail handled inside)
+            hipLaunchKernelGGL(k_temporal_acc, dim3((unsigned)((npix / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames, nframes,
+                               npix, sum_x, sum_xx);
+        } else {
+            hipLaunchKernelGGL(k_temporal_acc4, dim3((unsigned)((npix / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f0, nframes,
+                               frame_stride, npix, sum_x, sum_xx);
+        }
+    } else {   // odd pixel counts / unaligned views (the reference's data.mean(axis=0) takes any shape, io/rw.py:129-132)
+        hipLaunchKernelGGL(k_temporal_acc1, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f0, nframes,
+                           frame_stride, npix, sum_x, sum_xx);
+    }
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
@@ -733,7 +807,16 @@ int b4d_temporal_finalize(const double* sum_x, const double* sum_xx, double coun
     if (!sum_x || !sum_xx) return fail(B4D_EINVAL, "null argument");
     if (!(count > 0)) return fail(B4D_EINVAL, "count must be > 0");
     hipLaunchKernelGGL(k_temporal_fin, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sum_x,
-                       sum_xx, count, npix, mean, var, contrast);
+                       sum_xx, count, (const double*)nullptr, npix, mean, var, contrast);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int b4d_temporal_finalize_dev(const double* sum_x, const double* sum_xx, const double* count_dev, size_t npix, float* mean,
+                              float* var, float* contrast, void* stream) {
+    if (!sum_x || !sum_xx || !count_dev) return fail(B4D_EINVAL, "null argument");
+    hipLaunchKernelGGL(k_temporal_fin, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sum_x,
+                       sum_xx, 0.0, count_dev, npix, mean, var, contrast);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }

@@ -85,15 +85,19 @@ def temporal_stats_streamed(source, *, chunk_frames: int = 16, group=None, retur
     """metrics.temporal_stats over a host / memory-mapped stack streamed through iter_device_chunks: per-pixel
     mean, variance and contrast maps (float32) of ALL frames (and all ranks when a process group is given)."""
     torch = _ffi.require_gpu()
-    from .metrics import kernels as K
-    from .metrics.temporal import _reduce
+    from .metrics.temporal import TemporalSums, _dist_group
 
     T, H, W = (int(v) for v in source.shape)
-    sums = torch.zeros((2, H, W), dtype=torch.float64, device="cuda")
+    acc = TemporalSums(H, W, torch.device("cuda", torch.cuda.current_device()))
+    acc.add_count(T)
     for dev in iter_device_chunks(source, chunk_frames):
-        K.temporal_accumulate(dev, sums[0], sums[1])
-    sums, count = _reduce(sums, T, group)
-    mean, var, con = K.temporal_finalize(sums[0], sums[1], count)
+        acc.accumulate(dev)
+    dist = _dist_group(group)
+    if dist is not None:     # ONE all-reduce: the count rides in the sums' buffer
+        dist.all_reduce(acc.slice_for_reduce(0), op=dist.ReduceOp.SUM, group=group)
+    mean = torch.empty((H, W), dtype=torch.float32, device=acc.buf.device)
+    var, con = torch.empty_like(mean), torch.empty_like(mean)
+    acc.finalize(0, mean, var, con)
     if return_tensors:
         return mean, var, con
     return mean.cpu().numpy(), var.cpu().numpy(), con.cpu().numpy()

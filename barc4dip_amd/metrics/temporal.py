@@ -4,46 +4,134 @@ BASELINE.json config 4 / SURVEY.md §8 rows a23 + 8(e).  The reference only has 
 mean (``data.mean(axis=0)``, io/rw.py:129-132); variance and contrast follow the package's
 ddof=0 convention: mean_t = sum(x)/T, var_t = sum(x^2)/T - mean_t^2, contrast_t = sqrt(var_t)/mean_t.
 
-Each rank streams its own frames once (float64 accumulators, b4d_temporal_accumulate), then ONE
-all-reduce(sum) of the stacked (2, H, W) float64 sums + frame count crosses xGMI (RCCL through
-torch.distributed, backend "nccl"; "gloo" on CPU tensors for the logic tests).
+Each rank streams its own frames once (float64 accumulators, b4d_temporal_accumulate*), then ONE
+all-reduce(sum) crosses xGMI (RCCL through torch.distributed, backend "nccl"; "gloo" on CPU tensors for
+the logic tests): the frame count rides in the SAME float64 buffer as the sums,
+
+    buf = [count, 0, | sum_x rows of chunk 0 | sum_xx rows of chunk 0 | chunk 1 ... ]
+
+and ``b4d_temporal_finalize_dev`` reads it from device memory, so the host never waits for the collective.
+``overlap_chunks = k > 1`` splits the image rows into k blocks: block c is accumulated over all local frames,
+then its slice of ``buf`` is all-reduced on a side stream while block c + 1 is still being accumulated
+(the collective is 4-25 % of a cfg4 step at 8 GPUs) -- k collectives of 1/k of the payload each,
+the first one carrying the count.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 
 from .. import _ffi
-from . import kernels as K
 
 
-def _reduce(sums, count, group=None):
-    """All-reduce the (2, H, W) sums and the frame count.  No-op without an initialised process group."""
-    import torch
+def _dist_group(group):
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        cnt = torch.tensor([float(count)], dtype=torch.float64, device=sums.device)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
-        count = float(cnt.item())
-    return sums, count
+    if dist.is_available() and dist.is_initialized():   # a 1-rank group still runs the (trivial) collective: same code path
+        return dist
+    return None
 
 
-def temporal_stats(local_stack, *, group=None, chunk: int = 1024, return_tensors: bool = False):
+class TemporalSums:
+    """float64 accumulators of one rank in the packed, chunk-major layout described above."""
+
+    HEAD = 2   # [count, pad]: keeps every block 16-byte aligned
+
+    def __init__(self, H: int, W: int, device, chunks: int = 1):
+        import torch
+
+        self.H, self.W = int(H), int(W)
+        chunks = max(1, min(int(chunks), self.H))
+        edges = [round(i * self.H / chunks) for i in range(chunks + 1)]
+        self.rows = [(edges[i], edges[i + 1]) for i in range(chunks) if edges[i + 1] > edges[i]]
+        self.buf = torch.zeros(self.HEAD + 2 * self.H * self.W, dtype=torch.float64, device=device)
+        self.offsets = [self.HEAD + 2 * r0 * self.W for r0, _ in self.rows]
+
+    def block(self, c: int):
+        """(sum_x, sum_xx) views of row block c, each (rows, W)."""
+        r0, r1 = self.rows[c]
+        n = (r1 - r0) * self.W
+        o = self.offsets[c]
+        return self.buf[o:o + n].view(r1 - r0, self.W), self.buf[o + n:o + 2 * n].view(r1 - r0, self.W)
+
+    def slice_for_reduce(self, c: int):
+        """Contiguous slice of `buf` holding block c (block 0 also carries the count)."""
+        r0, r1 = self.rows[c]
+        o = self.offsets[c]
+        return self.buf[(0 if c == 0 else o):o + 2 * (r1 - r0) * self.W]
+
+    def add_count(self, n: int):
+        self.buf[0] += float(n)
+
+    def accumulate(self, frames, c: int | None = None, stream=None):
+        """sums += over `frames` (n, H, W) float32 device tensor; c = one row block, None = all of them."""
+        n, H, W = (int(v) for v in frames.shape)
+        assert (H, W) == (self.H, self.W) and frames.is_contiguous()
+        lib = _ffi.lib()
+        st = _ffi.stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+        for cc in (range(len(self.rows)) if c is None else (c,)):
+            r0, r1 = self.rows[cc]
+            sx, sxx = self.block(cc)
+            _ffi.check(lib.b4d_temporal_accumulate_range(C.c_void_p(frames.data_ptr()), n, H * W, r0 * W, (r1 - r0) * W,
+                                                         C.c_void_p(sx.data_ptr()), C.c_void_p(sxx.data_ptr()), st))
+
+    def finalize(self, c: int, mean, var, con):
+        """Row block c of the float32 maps from the (all-reduced) sums; the count comes from buf[0] on the device."""
+        r0, r1 = self.rows[c]
+        sx, sxx = self.block(c)
+        _ffi.check(_ffi.lib().b4d_temporal_finalize_dev(
+            C.c_void_p(sx.data_ptr()), C.c_void_p(sxx.data_ptr()), C.c_void_p(self.buf.data_ptr()), (r1 - r0) * self.W,
+            C.c_void_p(mean[r0:r1].data_ptr()), C.c_void_p(var[r0:r1].data_ptr()), C.c_void_p(con[r0:r1].data_ptr()),
+            _ffi.stream_ptr()))
+
+
+def temporal_stats(local_stack, *, group=None, chunk: int = 1024, overlap_chunks: int = 1, return_tensors: bool = False,
+                   timings: dict | None = None):
     """mean / variance / contrast maps over ALL frames of all ranks.
 
-    local_stack: this rank's frames (T_local, H, W), NumPy or ROCm tensor (float32 used).
+    local_stack: this rank's frames (T_local, H, W), NumPy or ROCm tensor (float32 used; any H, W).
+    overlap_chunks: row blocks whose all-reduce overlaps the accumulation of the following blocks (1 = one collective).
+    timings: optional dict receiving {"allreduce_ms": ...} (HIP events around the collective; forces a device sync).
     Returns (mean, var, contrast) float32 (H, W)."""
     torch = _ffi.require_gpu()
     from .. import _device as D
 
     t, _, _ = D.to_device_f32(local_stack, ndim=(3,))
     T, H, W = (int(v) for v in t.shape)
-    sums = torch.zeros((2, H, W), dtype=torch.float64, device=t.device)
-    for a in range(0, T, chunk):
-        K.temporal_accumulate(t[a:a + chunk], sums[0], sums[1])
-    sums, count = _reduce(sums, T, group)
-    mean, var, con = K.temporal_finalize(sums[0], sums[1], count)
+    dist = _dist_group(group)
+    acc = TemporalSums(H, W, t.device, overlap_chunks if dist is not None else 1)
+    acc.add_count(T)
+    mean = torch.empty((H, W), dtype=torch.float32, device=t.device)
+    var, con = torch.empty_like(mean), torch.empty_like(mean)
+    main = torch.cuda.current_stream()
+    nblk = len(acc.rows)
+    side = torch.cuda.Stream() if dist is not None and nblk > 1 else None
+    ev0 = ev1 = None
+    for c in range(nblk):
+        for a in range(0, T, chunk):
+            acc.accumulate(t[a:a + chunk], c)
+        if dist is None:
+            acc.finalize(c, mean, var, con)
+            continue
+        if side is None:      # ONE all-reduce of count + sums, on the caller's stream
+            if timings is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(main)
+            dist.all_reduce(acc.slice_for_reduce(c), op=dist.ReduceOp.SUM, group=group)
+            if ev1 is not None:
+                ev1.record(main)
+            acc.finalize(c, mean, var, con)
+        else:                 # block c's collective + finalize on the side stream, block c + 1 accumulates meanwhile
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dist.all_reduce(acc.slice_for_reduce(c), op=dist.ReduceOp.SUM, group=group)
+                acc.finalize(c, mean, var, con)
+    if side is not None:
+        main.wait_stream(side)
+    if timings is not None and ev1 is not None:
+        ev1.synchronize()
+        timings["allreduce_ms"] = float(ev0.elapsed_time(ev1))
     if return_tensors:
         return mean, var, con
     return mean.cpu().numpy(), var.cpu().numpy(), con.cpu().numpy()
@@ -57,10 +145,18 @@ def shard_bounds(total_frames: int, world_size: int, rank: int) -> tuple[int, in
 
 
 def reduce_sums_cpu(sum_x: np.ndarray, sum_xx: np.ndarray, count: int, group=None):
-    """The same collective on host float64 arrays (gloo) -- used by the multi-process CPU tests of
-    the sharding/reduction logic; returns (sum_x, sum_xx, count) over all ranks."""
+    """The same packed collective on host float64 arrays (gloo) -- used by the multi-process CPU tests of the
+    sharding / reduction logic: ONE all-reduce of [count, pad, sum_x, sum_xx]; returns (sum_x, sum_xx, count) over all ranks."""
     import torch
 
-    s = torch.from_numpy(np.stack([sum_x, sum_xx]).astype(np.float64))
-    s, c = _reduce(s, count, group)
-    return s[0].numpy(), s[1].numpy(), c
+    n = sum_x.size
+    buf = torch.zeros(TemporalSums.HEAD + 2 * n, dtype=torch.float64)
+    buf[0] = float(count)
+    buf[TemporalSums.HEAD:TemporalSums.HEAD + n] = torch.from_numpy(np.ascontiguousarray(sum_x, dtype=np.float64).ravel())
+    buf[TemporalSums.HEAD + n:] = torch.from_numpy(np.ascontiguousarray(sum_xx, dtype=np.float64).ravel())
+    dist = _dist_group(group)
+    if dist is not None:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    out = buf.numpy()
+    return (out[TemporalSums.HEAD:TemporalSums.HEAD + n].reshape(sum_x.shape).copy(),
+            out[TemporalSums.HEAD + n:].reshape(sum_xx.shape).copy(), float(out[0]))

@@ -8,7 +8,12 @@ written for every frame).  Metric: frames/s (whole job, all ranks), plus
   * roofline: the dominant kernel (column FFT/PSD/inverse) priced by HIP events inside the
     timed region, against the 8 TB/s HBM roof (DESIGN.md states the byte accounting);
   * cpu_baseline: the NumPy oracle (port of the reference's fft2d + psd2d + autocorr2d calls)
-    timed on the host cores of this box on a bounded sample.
+    timed on the host cores of this box on a bounded sample;
+  * secondary: the other BASELINE.json configs, measured AFTER the timed region of the headline
+    (they never touch `value`): cfg3 phase-correlation tracking (1024^2), cfg4 temporal statistics
+    (this rank's 2048^2 shard + ONE all-reduce over RCCL when --gpus N > 1) and cfg5 Wiener
+    deconvolution (4096^2, sigma 1.5), each with its SURVEY.md §8(d) byte model, the fraction of the
+    8 TB/s roof and the error against the oracle on a small sample.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -30,6 +35,7 @@ sys.path.insert(0, ROOT)
 N = 2048
 FRAMES_PER_GPU = 256
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_FILE = "profiles/r02_pmc_col.json"
 
 
 def baseline_metric() -> str:
@@ -37,7 +43,7 @@ def baseline_metric() -> str:
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
-        return "frames/s (2048\u00d72048 fp32) through FFT\u2192PSD\u2192autocorr; % HBM roofline"
+        return "frames/s (2048×2048 fp32) through FFT→PSD→autocorr; % HBM roofline"
 
 
 def algorithmic_bytes(n: int):
@@ -85,6 +91,171 @@ def cpu_baseline(n: int, frames: int):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- secondary configs
+def _best_of(fn, sync, reps):
+    fn()
+    sync()
+    best = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def secondary_cfg3(torch, cpu: bool):
+    """BASELINE configs[2]: phase-correlation tracking on a 1024 x 1024 stack, SURVEY.md §8(d) protocol: 3 x 3 ROI grid,
+    "abs" (template from frame 0) and "inc" (template from the previous frame) = 18 pairs per frame.  64 frames of the
+    1024-frame stack are resident (the rate does not depend on T: every frame is transformed once, every pair once)."""
+    from barc4dip_amd import synth
+    from barc4dip_amd.geometry import roi_grid_3x3
+    from barc4dip_amd.signal import phase_correlation_batch
+
+    T, n, side = 64, 1024, 121
+    stack, sh = synth.shifted_stack(T, n, seed=1234, max_shift=32)
+    dev = torch.from_numpy(stack).cuda()
+    grid, _ = roi_grid_3x3((n, n), (side, side), (side // 2, side // 2))
+    rois = [(s[0].start, s[0].stop, s[1].start, s[1].stop) for s in grid.ravel()]
+    tpl_frame = [0] * 9 + [max(t - 1, 0) for t in range(T) for _ in range(9)]
+    tpl_roi = rois + rois * T
+    pair_img = [t for t in range(T) for _ in range(9)] * 2
+    pair_tpl = [k for _ in range(T) for k in range(9)] + [9 + 9 * t + k for t in range(T) for k in range(9)]
+    res = {}
+
+    def run():
+        res["out"] = phase_correlation_batch(dev, dev, tpl_frame, tpl_roi, pair_img, pair_tpl)
+
+    best = _best_of(run, torch.cuda.synchronize, 3)
+    out = res["out"]
+    npairs = len(pair_img)
+    truth = bool(np.all(np.median(np.rint(out[:9 * T, 0]).reshape(T, 9), axis=1) == sh[:, 0]) and
+                 np.all(np.median(np.rint(out[:9 * T, 1]).reshape(T, 9), axis=1) == sh[:, 1]))
+    nh = n // 2 + 1
+    bytes_pair = 12 * n * n + 56 * n * nh
+    line = {"workload": f"cfg3: phase-correlation tracking, {T} resident frames of {n}x{n}, 3x3 ROI grid abs + inc ({npairs} pairs)",
+            "pairs_per_s": npairs / best, "frames_per_s": T / best, "bytes_per_pair": bytes_pair,
+            "achieved_GBps": bytes_pair * npairs / best / 1e9, "frac": bytes_pair * npairs / best / 1e9 / HBM_PEAK_GBS,
+            "ground_truth_recovered": truth}
+    if cpu:
+        from oracle import signal_np as S
+
+        t0 = time.perf_counter()
+        worst_sub, int_ok, k = 0.0, True, 0
+        for t in (1, T - 1):
+            for ri in (0, 4):
+                r = rois[ri]
+                sl = (slice(r[0], r[1]), slice(r[2], r[3]))
+                ref = S.phase_correlation(stack[0][sl].astype(np.float64), stack[t].astype(np.float64), slices_yx=sl)
+                got = out[9 * t + ri]
+                int_ok &= (round(ref[0]) == round(got[0])) and (round(ref[1]) == round(got[1]))
+                worst_sub = max(worst_sub, abs(ref[0] - got[0]), abs(ref[1] - got[1]))
+                k += 1
+        dt = time.perf_counter() - t0
+        line.update({"max_subpixel_err_vs_oracle_px": worst_sub, "integer_shifts_equal_oracle": bool(int_ok),
+                     "cpu_port_pairs_per_s": k / dt, "cpu_sample": f"{k} pairs, float64 oracle, 1 core"})
+    return line
+
+
+def secondary_cfg5(torch, cpu: bool):
+    """BASELINE configs[4]: Gaussian-PSF Wiener deconvolution of 4096 x 4096 frames, sigma 1.5 (padded 4104^2), T = 32
+    resident frames, through the public deconvolve_psf with device tensors in and out."""
+    from barc4dip_amd import synth
+    from barc4dip_amd.preprocessing import deconvolve_psf
+
+    T, n, sigma = 32, 4096, 1.5
+    dev = synth.speckle_stack_device(T, n, seed0=4321)
+    res = {}
+
+    def run():
+        res["out"] = deconvolve_psf(dev, sigma=sigma, return_tensors=True)
+
+    best = _best_of(run, torch.cuda.synchronize, 3)
+    m, mh = n + 8, (n + 8) // 2 + 1
+    bytes_frame = 12 * m * m + 48 * m * mh + 4 * n * n
+    line = {"workload": f"cfg5: Wiener deconvolution, {T} resident frames of {n}x{n}, sigma {sigma} (padded {m}x{m} = 8*27*19)",
+            "frames_per_s": T / best, "bytes_per_frame": bytes_frame, "achieved_GBps": bytes_frame * T / best / 1e9,
+            "frac": bytes_frame * T / best / 1e9 / HBM_PEAK_GBS}
+    if cpu:
+        from oracle import wiener_np as W
+
+        host = dev[0].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = W.deconvolve_psf(host, sigma=sigma)
+        dt = time.perf_counter() - t0
+        line.update({"max_err_vs_oracle_over_range": float(np.max(np.abs(res["out"][0].cpu().numpy() - ref)) / np.max(np.abs(host))),
+                     "cpu_port_frames_per_s": 1.0 / dt, "cpu_sample": "1 frame, float32 oracle (parity unpinned: scikit-image absent), 1 core"})
+    del dev, res
+    torch.cuda.empty_cache()
+    return line
+
+
+def secondary_cfg4(torch, dist, stack, world: int, rank: int, cpu: bool):
+    """BASELINE configs[3]: per-pixel temporal mean / variance / contrast.  Every rank streams ITS frames (the cfg2 stack,
+    256 frames of 2048^2 per GPU) into float64 sums, then ONE all-reduce of [count, sum_x, sum_xx] (64 MiB) crosses xGMI
+    (RCCL) and the maps are finalised from the reduced sums.  Reported: whole-job frames/s, the collective's own time,
+    and equality of the N-rank result with a single-rank run on a small stack."""
+    from barc4dip_amd.metrics.temporal import shard_bounds, temporal_stats
+
+    T, H, W = (int(v) for v in stack.shape)
+    tm = {}
+
+    def run():
+        temporal_stats(stack, return_tensors=True, timings=tm if world > 1 else None)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64))   # gloo: host-side rendezvous
+
+    run()
+    sync()
+    best = 1e30
+    for _ in range(3):
+        sync()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        best = min(best, dt)
+    bytes_frame = 4 * H * W
+    line = {"workload": f"cfg4: temporal mean/var/contrast, {T} frames of {H}x{W} per GPU x {world} GPU(s), "
+                        + ("one RCCL all-reduce of 2*H*W+2 float64" if world > 1 else "no collective at N = 1"),
+            "frames_per_s": T * world / best, "bytes_per_frame": bytes_frame,
+            "achieved_GBps_per_gpu": bytes_frame * T / best / 1e9, "frac": bytes_frame * T / best / 1e9 / HBM_PEAK_GBS,
+            "allreduce_ms": tm.get("allreduce_ms"), "allreduce_payload_bytes": 8 * (2 * H * W + 2) if world > 1 else 0}
+    # correctness on a small stack that every rank can generate: N-rank sharded result == single-rank result, and both
+    # against the float64 NumPy expressions (oracle/temporal_np.py)
+    Ts = 8 * world + 3
+    rng = np.random.default_rng(77)
+    small = rng.poisson(900.0, size=(Ts, 96, 128)).astype(np.float32)
+    t0, t1 = shard_bounds(Ts, world, rank)
+    got = [x.cpu().numpy() for x in temporal_stats(torch.from_numpy(small[t0:t1]).cuda(), return_tensors=True, overlap_chunks=3)]
+    if rank == 0:
+        if world > 1:
+            solo = dist.new_group([0])
+        one = [x.cpu().numpy() for x in temporal_stats(torch.from_numpy(small).cuda(), return_tensors=True,
+                                                        group=solo if world > 1 else None)]
+        line["n_rank_equals_single_rank"] = bool(all(np.array_equal(a, b) for a, b in zip(got, one)))
+        if cpu:
+            from oracle import temporal_np as Tn
+
+            ref = Tn.temporal_stats(small)
+            line["max_rel_err_vs_oracle"] = float(max(np.max(np.abs(a - r) / np.maximum(np.abs(r), 1e-30)) for a, r in zip(got, ref)))
+            host = stack[:16].cpu().numpy()
+            tc = time.perf_counter()
+            Tn.temporal_stats(host)
+            line["cpu_port_frames_per_s"] = 16 / (time.perf_counter() - tc)
+            line["cpu_sample"] = "16 frames of 2048x2048, NumPy float64 sums, 1 core"
+    elif world > 1:
+        dist.new_group([0])   # collective: every rank takes part in the creation of rank 0's solo group
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +265,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="frames per launch group (0 = library default)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / cfg4 / cfg5 block after the timed region")
     args = ap.parse_args()
 
     import torch
@@ -110,8 +282,8 @@ def main():
         # one node by contract: keep every rendezvous on the loopback interface (the container hostname may not resolve)
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        # one process per GPU; RCCL ("nccl") carries device collectives (none on this data path: frames are
-        # sharded, nothing is exchanged), gloo carries the host-side barrier and the max-over-ranks of the timing
+        # one process per GPU; RCCL ("nccl") carries device collectives (the cfg4 all-reduce; the cfg2 data path has none:
+        # frames are sharded, nothing is exchanged), gloo carries the host-side barrier and the max-over-ranks of the timing
         dist.init_process_group(backend="cpu:gloo,cuda:nccl")
 
     from barc4dip_amd import _ffi, synth
@@ -152,6 +324,25 @@ def main():
     # sanity on the product of the timed region (not a parity test): peak == 1 at the centre of every frame
     centre = ac[:, N // 2, N // 2]
     ok = bool(torch.all(centre == 1.0).item()) and bool(torch.isfinite(psd[0]).all().item())
+    plan.close()
+    del psd, ac, plan
+    torch.cuda.empty_cache()
+
+    secondary = None
+    if not args.no_secondary:
+        cpu = not args.no_cpu
+        secondary = {"note": "measured after the timed region of the headline; never part of `value`; HBM roof 8 TB/s; "
+                             "byte models: SURVEY.md §8(d)"}
+        c4 = secondary_cfg4(torch, dist, stack, world, rank, cpu)
+        if rank == 0:
+            secondary["cfg4"] = c4
+        if world == 1:
+            del stack
+            torch.cuda.empty_cache()
+            secondary["cfg3"] = secondary_cfg3(torch, cpu)
+            secondary["cfg5"] = secondary_cfg5(torch, cpu)
+        else:
+            secondary["cfg3"] = secondary["cfg5"] = "measured at --gpus 1 only (frames are sharded, no collective: N ranks run N copies)"
 
     if rank == 0:
         B = algorithmic_bytes(N)
@@ -161,11 +352,13 @@ def main():
         col_ms = kms[1] / nlaunch
         frames_per_launch = T / ((T + chunk - 1) // chunk)
         col_gbs = B["col"] * frames_per_launch / (col_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_col.json")
+        traffic, traffic_source = None, None
+        pmc_path = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc_path):
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                traffic_source = (f"{PMC_FILE} (static: a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of this bench at "
+                                  "64 frames per launch, NOT measured by the process that printed this line)")
             except Exception:
                 traffic = None
         line = {
@@ -178,7 +371,8 @@ def main():
                        "frames_per_gpu": T, "chunk": chunk, "parallelism": f"frames sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": "k_col (column FFT + |F|^2 PSD + inverse column FFT, fused)",
                          "achieved": col_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": col_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "bytes_per_launch": B["col"] * frames_per_launch,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "bytes_per_launch": B["col"] * frames_per_launch,
                          "avg_launch_ms": col_ms,
                          "kernel_ms_per_step": {"row_r2c": kms[0] / args.steps, "col": kms[1] / args.steps,
                                                 "peak": kms[2] / args.steps, "row_c2r": kms[3] / args.steps}},
@@ -188,13 +382,16 @@ def main():
                                   "note": "SURVEY.md §8(d): B_pipe = 12N^2 + 40 N (N/2+1) per frame"},
             "outputs_ok": ok,
         }
+        if secondary is not None:
+            line["secondary"] = secondary
         if not args.no_cpu and world == 1:     # the CPU leg is timed at N = 1 only (it would idle the other ranks)
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_frames)
         print(json.dumps(line), flush=True)
-    plan.close()
     if world > 1:
         dist.all_reduce(torch.zeros(1, dtype=torch.float64))
         dist.destroy_process_group()
+    if not ok:      # a wrong product of the timed region must not look like a measurement
+        sys.exit(3)
 
 
 if __name__ == "__main__":

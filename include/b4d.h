@@ -124,12 +124,21 @@ int b4d_template_match(b4d_plan* plan, const float* images, int nimg, const floa
 
 /* Temporal per-pixel statistics (io/rw.py:129-132 for the mean).
  * accumulate: sum_x += sum_t x, sum_xx += sum_t x^2 over `nframes` frames of npix pixels
- * (float64 accumulators, caller zero-initialises).  finalize: mean, var (ddof 0),
+ * (float64 accumulators, caller zero-initialises; any npix / alignment).  finalize: mean, var (ddof 0),
  * contrast = sqrt(var)/mean as float32 maps from the (all-reduced) sums.                */
 int b4d_temporal_accumulate(const float* frames, int nframes, size_t npix, double* sum_x, double* sum_xx,
                             void* stream);
 int b4d_temporal_finalize(const double* sum_x, const double* sum_xx, double count, size_t npix, float* mean,
                           float* var, float* contrast, void* stream);
+/* accumulate on pixels [pix0, pix0 + npix) of frames that are frame_stride pixels apart (row chunks of an image, so that
+ * the all-reduce of finished rows overlaps the accumulation of the rest); sum_x / sum_xx point at the
+ * accumulators of pixel pix0.  Any pixel count and alignment (odd frame sizes take a dword kernel). */
+int b4d_temporal_accumulate_range(const float* frames, int nframes, size_t frame_stride, size_t pix0, size_t npix,
+                                  double* sum_x, double* sum_xx, void* stream);
+/* finalize with the frame count read from DEVICE memory: the count travels in the same all-reduced float64 buffer as the
+ * sums, so the host never waits for it. */
+int b4d_temporal_finalize_dev(const double* sum_x, const double* sum_xx, const double* count_dev, size_t npix, float* mean,
+                              float* var, float* contrast, void* stream);
 
 /* metrics/statistics.py:17-125 distribution_moments + speckles.py:640-645 visibility inputs:
  * per-frame finite-only power sums in float64.

@@ -36,6 +36,21 @@ def test_header_library_binding_agree(lib):
     assert set(syms) <= exported
 
 
+def test_library_is_not_a_timing_only_build(lib):
+    """B4D_EXP_* switches (wrong results on purpose, used to price one ingredient of a kernel in A/B runs) compile only
+    under -DB4D_TIMING_ONLY (csrc/b4d_timing_only.hpp), which stamps b4d_version(): such a library is refused here."""
+    v = lib.b4d_version()
+    assert b"TIMING" not in v and b"EXP" not in v, v
+    src = os.path.join(ROOT, "barc4dip_amd", "csrc")
+    guard = open(os.path.join(src, "b4d_timing_only.hpp")).read()
+    used = set()
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".hpp")) and f != "b4d_timing_only.hpp":
+            used |= set(re.findall(r"#\s*(?:ifdef|ifndef|if|elif)[^\n]*\b(B4D_EXP_[A-Z0-9_]+)", open(os.path.join(src, f)).read()))
+    missing = [m for m in sorted(used) if m not in guard]
+    assert missing == [], f"timing-only switches not covered by the B4D_TIMING_ONLY guard: {missing}"
+
+
 def test_no_gpu_calls_needed_for_introspection(lib):
     assert lib.b4d_version().startswith(b"b4d ")
     assert lib.b4d_size_supported(2048, 2048) == 1

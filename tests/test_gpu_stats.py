@@ -93,3 +93,55 @@ def test_streamed_ingest_equals_resident(tmp_path):
         assert torch.equal(torch.cat(seen), torch.from_numpy(stack.astype(np.float32)).cuda())
     with pytest.raises(ValueError):
         list(ingest.iter_device_chunks(stack[0], 4))
+
+
+@pytest.mark.parametrize("shape", [(5, 33, 31), (7, 101, 127), (3, 64, 66), (9, 1, 5)])
+def test_temporal_stats_any_frame_shape(shape):
+    """The reference's data.mean(axis=0) (io/rw.py:129-132) takes any frame shape: odd pixel counts and frames that
+    do not start on 16-byte boundaries take the dword kernel (b4d_temporal_accumulate_range)."""
+    import torch
+
+    from barc4dip_amd.metrics import temporal_stats
+    from oracle import temporal_np as Tn
+
+    rng = np.random.default_rng(shape[1] * 100 + shape[2])
+    stack = rng.poisson(700.0, size=shape).astype(np.float32)
+    for chunk in (2, 1024):
+        got = temporal_stats(stack, chunk=chunk)
+        for g, r in zip(got, Tn.temporal_stats(stack)):
+            assert g.shape == shape[1:] and g.dtype == np.float32
+            np.testing.assert_allclose(g, r, rtol=2e-6, atol=1e-6)
+    view = torch.from_numpy(np.concatenate([np.zeros(1, np.float32), stack.ravel()])).cuda()[1:].view(shape)   # 4-byte offset
+    got2 = temporal_stats(view, return_tensors=True)
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(got2, got))
+
+
+def test_temporal_stats_packed_allreduce_and_row_block_overlap():
+    """cfg4's collective on RCCL (a 1-rank group on this one-GPU box: same calls, same streams): the count rides in the
+    float64 buffer of the sums (ONE all-reduce), and with overlap_chunks > 1 every row block is reduced on a side stream
+    while the next one accumulates; both must reproduce the plain single-process result bit for bit."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from barc4dip_amd import synth
+    from barc4dip_amd.metrics import temporal_stats
+
+    stack = torch.from_numpy(synth.speckle_stack(12, 256, seed0=3)[:, :250, :252].copy()).cuda()
+    plain = [x.cpu().numpy() for x in temporal_stats(stack, return_tensors=True)]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29871")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        tm = {}
+        one = [x.cpu().numpy() for x in temporal_stats(stack, return_tensors=True, timings=tm)]
+        assert "allreduce_ms" in tm and tm["allreduce_ms"] >= 0.0
+        blocks = [x.cpu().numpy() for x in temporal_stats(stack, return_tensors=True, overlap_chunks=5, chunk=5)]
+    finally:
+        if created:
+            dist.destroy_process_group()
+    for a, b, c in zip(plain, one, blocks):
+        assert np.array_equal(a, b) and np.array_equal(a, c)

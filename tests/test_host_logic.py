@@ -83,3 +83,27 @@ def test_default_chunk_policy():
     assert _ffi.default_chunk(1024, 1024) == 128
     assert 1 <= _ffi.default_chunk(64, 64) <= 128
     assert _ffi.default_chunk(228, 227) == 128 and _ffi.default_chunk(512, 500) >= 32
+
+
+def test_temporal_sums_layout_is_one_contiguous_buffer():
+    """metrics/temporal.py: [count, pad | block 0 | block 1 ...], every block = (sum_x rows, sum_xx rows); the slices
+    handed to the collective tile the buffer exactly once and the first one carries the count."""
+    import torch
+
+    from barc4dip_amd.metrics.temporal import TemporalSums
+
+    for H, W, k in ((10, 7, 1), (10, 7, 3), (5, 4, 9), (2048, 8, 4)):
+        acc = TemporalSums(H, W, torch.device("cpu"), k)
+        assert acc.buf.numel() == 2 + 2 * H * W and acc.rows[0][0] == 0 and acc.rows[-1][1] == H
+        assert all(a[1] == b[0] for a, b in zip(acc.rows, acc.rows[1:]))
+        acc.add_count(5)
+        covered = torch.zeros_like(acc.buf)
+        for c in range(len(acc.rows)):
+            sl = acc.slice_for_reduce(c)
+            assert sl.is_contiguous() and sl.data_ptr() >= acc.buf.data_ptr()
+            covered[(sl.data_ptr() - acc.buf.data_ptr()) // 8:][:sl.numel()] += 1
+            sx, sxx = acc.block(c)
+            assert sx.shape == sxx.shape == (acc.rows[c][1] - acc.rows[c][0], W)
+            assert sx.data_ptr() % 16 == acc.buf.data_ptr() % 16
+        assert torch.all(covered == 1)
+        assert float(acc.slice_for_reduce(0)[0]) == 5.0
