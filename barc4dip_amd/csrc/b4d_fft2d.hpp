@@ -257,12 +257,16 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
     const int kx0 = ct * CT + NC * cpm;
 
     if (MODE == COL_FORWARD) {  // keep the 2-D half spectrum in the tile
+        // laundered offset: otherwise the 16 store addresses (= the load addresses) stay live in 32 registers across the
+        // whole transform and the radix stages spill (8 dwords at 512 rows ... 28 at 4096)
+        unsigned toff3 = toff;
+        asm volatile("" : "+v"(toff3));
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             float2 c[NC];
 #pragma unroll
             for (int k = 0; k < NC; ++k) c[k] = v[k][j];
-            store_cols<NC>(tile + (size_t)(T * j * CT) + toff, c);
+            store_cols<NC>(tile + (size_t)(T * j * CT) + toff3, c);
         }
         return;
     }

@@ -119,12 +119,14 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS, ColCfg<NY>::WAVES_PER_EU)
         }
     }
     Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL, true, Cfg::SB>(v, u, cp, lds, p.tw);
+    unsigned toff2 = toff;   // laundered: the store addresses are not kept live across the transform (spills otherwise)
+    asm volatile("" : "+v"(toff2));
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         float2 c[NC];
 #pragma unroll
         for (int k = 0; k < NC; ++k) c[k] = make_float2(v[k][j].y, v[k][j].x);
-        store_cols<NC>(tg + (size_t)(T * j * CT) + toff, c);
+        store_cols<NC>(tg + (size_t)(T * j * CT) + toff2, c);
     }
 }
 
