@@ -494,6 +494,9 @@ struct RowOutArgs {
     unsigned flags;
     float* part_val;     // C2R_MAG: per-workgroup arg-max partials (batch, gridDim.x)
     int* part_idx;
+    unsigned* hist;      // C2R_MAG, optional: (batch, 2048) counts of the magnitudes' top 11 key bits (first pass of the
+                         // exact median's radix select, b4d_select.hpp), accumulated with one global atomic per non-empty
+                         // bin and workgroup; zeroed by the caller
     int half;            // C2R_OUT: the map is even (R[-y,-x] = R[y,x], autocorrelation): transform rows 0..ny/2 only
                          // and write every row together with its point mirror
 };
@@ -613,6 +616,35 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
         for (int i = 1; i < nw; ++i) argmax_merge(bv, bi, sv[i], si[i]);
         p.part_val[frame * gridDim.x + blockIdx.x] = bv;
         p.part_idx[frame * gridDim.x + blockIdx.x] = bi;
+    }
+    if (p.hist) {
+        // First pass of the median's radix select, fused into the pass that produces the map: one 2048-bin histogram per
+        // wave in the (now free) exchange buffer -- magnitudes crowd ~10 bins, so a wave's atomics conflict with each other
+        // but never with another wave's --, folded and pushed with one global atomic per non-empty bin.
+        constexpr int NW = (T * SEQ + 63) / 64;
+        constexpr int HIST_WORDS = 2048 * NW;
+        static_assert(sizeof(lds_all) >= sizeof(unsigned) * (64 + HIST_WORDS) || NW == 0, "exchange buffer too small for the histograms");
+        unsigned* hl = reinterpret_cast<unsigned*>(lds_all) + 64;   // words 0..63: the arg-max partials above
+        __syncthreads();
+        for (int i = threadIdx.x; i < HIST_WORDS; i += T * SEQ) hl[i] = 0;
+        __syncthreads();
+        if (live) {
+            unsigned* mine = hl + 2048 * w;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const float m0 = fabsf(v[j].y * p.scale), m1 = fabsf(v[j].x * p.scale);
+                if (m0 == m0) atomicAdd(&mine[(__float_as_uint(m0) | 0x80000000u) >> 21], 1u);   // f2key of a value >= 0
+                if (m1 == m1) atomicAdd(&mine[(__float_as_uint(m1) | 0x80000000u) >> 21], 1u);
+            }
+        }
+        __syncthreads();
+        unsigned* gh = p.hist + frame * 2048;
+        for (int i = threadIdx.x; i < 2048; i += T * SEQ) {
+            unsigned t = hl[i];
+#pragma unroll
+            for (int r = 1; r < NW; ++r) t += hl[2048 * r + i];
+            if (t) atomicAdd(&gh[i], t);
+        }
     }
 }
 

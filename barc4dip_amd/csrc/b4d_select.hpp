@@ -22,15 +22,18 @@ __device__ __forceinline__ float key2f(unsigned k) {
 // compact (optional, >= n floats of global scratch owned by this workgroup): after the first pass the elements of the
 // selected 11-bit bin are gathered there and the two remaining passes (and the caller's next_larger_key) stream that
 // short array instead of the whole map; *cx / *cn return the array / length to continue on.
+// pass_begin = 1 resumes after a first pass done elsewhere (k_row_c2r's fused histogram + k_track_gather): x then
+// holds only the elements of the selected top-11-bit bin `prefix0 >> 21`, below0 = number of elements under that bin.
 template <int REP = 1>
 __device__ inline unsigned radix_select(const float* __restrict__ x, unsigned n, unsigned k, unsigned* hist,
                                         unsigned* sh, unsigned& n_less, unsigned& n_equal, float* __restrict__ compact = nullptr,
-                                        const float** cx = nullptr, unsigned* cn = nullptr) {
-    unsigned prefix = 0, mask = 0, below = 0;
+                                        const float** cx = nullptr, unsigned* cn = nullptr, int pass_begin = 0, unsigned prefix0 = 0,
+                                        unsigned below0 = 0) {
+    unsigned prefix = prefix0, mask = pass_begin ? 0xffe00000u : 0u, below = below0;
     unsigned* myhist = hist + (threadIdx.x % REP) * 2048;
     const int shifts[3] = {21, 10, 0};
     const int widths[3] = {11, 11, 10};
-    for (int pass = 0; pass < 3; ++pass) {
+    for (int pass = pass_begin; pass < 3; ++pass) {
         const int sft = shifts[pass], nb = 1 << widths[pass];
         for (int i = threadIdx.x; i < 2048 * REP; i += blockDim.x) hist[i] = 0;
         __syncthreads();

@@ -148,6 +148,42 @@ struct FinArgs {
     float* compact;         // optional (pairs, stride) scratch for the median's gathered bin (b4d_select.hpp)
 };
 
+// peak quality + Taylor step of one pair (one lane), op for op like tracking.py:314-375 (float32 scalars, no contraction)
+__device__ inline void track_finish(const FinArgs& p, size_t pair, const float* __restrict__ mag, int mny, int mnx, int oy, int ox,
+                                    float bv, int bi, float med) {
+    const int mi = bi / mnx, mj = bi % mnx;
+    const double peak = (double)bv;
+    const double snr = fabs(peak) / ((double)med + p.eps);
+    double dy = (double)(mi - oy), dx = (double)(mj - ox);
+    if (p.subpixel && mi > 0 && mi < mny - 1 && mj > 0 && mj < mnx - 1) {
+        auto c = [&](int di, int dj) { return mag[(size_t)(mi + di) * mnx + (mj + dj)]; };
+        const float c00 = c(0, 0);
+        const float gy = __fdiv_rn(__fsub_rn(c(1, 0), c(-1, 0)), 2.0f);
+        const float hyy = __fsub_rn(__fadd_rn(c(1, 0), c(-1, 0)), __fmul_rn(2.0f, c00));
+        const float gx = __fdiv_rn(__fsub_rn(c(0, 1), c(0, -1)), 2.0f);
+        const float hxx = __fsub_rn(__fadd_rn(c(0, 1), c(0, -1)), __fmul_rn(2.0f, c00));
+        const float hxy = __fdiv_rn(__fadd_rn(__fsub_rn(__fsub_rn(c(1, 1), c(1, -1)), c(-1, 1)), c(-1, -1)), 4.0f);
+        const float det = __fsub_rn(__fmul_rn(hxx, hyy), __fmul_rn(hxy, hxy));
+        if (det != 0.0f) {
+            const float inv = __fdiv_rn(1.0f, det);
+            // NOTE the reference's swapped corrections (tracking.py:372-373), reproduced on purpose
+            const float di = __fmul_rn(-__fsub_rn(__fmul_rn(hyy, gx), __fmul_rn(hxy, gy)), inv);
+            const float dj = __fmul_rn(-__fsub_rn(__fmul_rn(hxx, gy), __fmul_rn(hxy, gx)), inv);
+            dy += (double)di;
+            dx += (double)dj;
+        }
+    }
+    double* o = p.out + pair * 4;
+    o[0] = dy;
+    o[1] = dx;
+    o[2] = peak;
+    o[3] = snr;
+    if (p.peak_ij) {
+        p.peak_ij[pair * 2] = mi;
+        p.peak_ij[pair * 2 + 1] = mj;
+    }
+}
+
 // grid (pairs), block 1024, dynamic LDS FIN_LDS bytes
 constexpr int FIN_REP = 4;
 constexpr size_t FIN_LDS = sizeof(unsigned) * 2048 * FIN_REP;
@@ -208,38 +244,7 @@ __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
         med = __fmul_rn(__fadd_rn(a, b), 0.5f);
     }
     if (threadIdx.x != 0) return;
-    // ---- peak quality + Taylor step, op for op like tracking.py:314-375 (float32 scalars, no contraction)
-    const int mi = bi / mnx, mj = bi % mnx;
-    const double peak = (double)bv;
-    const double snr = fabs(peak) / ((double)med + p.eps);
-    double dy = (double)(mi - oy), dx = (double)(mj - ox);
-    if (p.subpixel && mi > 0 && mi < mny - 1 && mj > 0 && mj < mnx - 1) {
-        auto c = [&](int di, int dj) { return mag[(size_t)(mi + di) * mnx + (mj + dj)]; };
-        const float c00 = c(0, 0);
-        const float gy = __fdiv_rn(__fsub_rn(c(1, 0), c(-1, 0)), 2.0f);
-        const float hyy = __fsub_rn(__fadd_rn(c(1, 0), c(-1, 0)), __fmul_rn(2.0f, c00));
-        const float gx = __fdiv_rn(__fsub_rn(c(0, 1), c(0, -1)), 2.0f);
-        const float hxx = __fsub_rn(__fadd_rn(c(0, 1), c(0, -1)), __fmul_rn(2.0f, c00));
-        const float hxy = __fdiv_rn(__fadd_rn(__fsub_rn(__fsub_rn(c(1, 1), c(1, -1)), c(-1, 1)), c(-1, -1)), 4.0f);
-        const float det = __fsub_rn(__fmul_rn(hxx, hyy), __fmul_rn(hxy, hxy));
-        if (det != 0.0f) {
-            const float inv = __fdiv_rn(1.0f, det);
-            // NOTE the reference's swapped corrections (tracking.py:372-373), reproduced on purpose
-            const float di = __fmul_rn(-__fsub_rn(__fmul_rn(hyy, gx), __fmul_rn(hxy, gy)), inv);
-            const float dj = __fmul_rn(-__fsub_rn(__fmul_rn(hxx, gy), __fmul_rn(hxy, gx)), inv);
-            dy += (double)di;
-            dx += (double)dj;
-        }
-    }
-    double* o = p.out + pair * 4;
-    o[0] = dy;
-    o[1] = dx;
-    o[2] = peak;
-    o[3] = snr;
-    if (p.peak_ij) {
-        p.peak_ij[pair * 2] = mi;
-        p.peak_ij[pair * 2 + 1] = mj;
-    }
+    track_finish(p, pair, mag, mny, mnx, oy, ox, bv, bi, med);
 }
 
 static int launch_track_fin(const FinArgs& fa, int pairs, hipStream_t st) {
@@ -250,6 +255,176 @@ static int launch_track_fin(const FinArgs& fa, int pairs, hipStream_t st) {
     });
     B4D_HIP(attr_err);
     hipLaunchKernelGGL(k_track_fin, dim3(pairs), dim3(1024), FIN_LDS, st, fa);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+// ---- phase correlation: the median's first select pass comes from k_row_c2r (one global 2048-bin histogram per pair), the
+// bin's elements are gathered by SEVERAL workgroups per pair (one streamed read of the map over the whole chip), and one
+// workgroup per pair finishes on the gathered ~10 % of the map: passes 2-3 of the select, arg-max partials, Taylor step.
+struct SelState {
+    unsigned bin, below, count, fill;   // selected top-11-bit bin, elements under it, elements in it, gather cursor
+};
+constexpr int GATHER_SPLIT = 8;
+constexpr int GATHER_STAGE = 8192;   // floats staged in LDS between two flushes (a power-of-two multiple of 1024)
+
+// grid (GATHER_SPLIT, pairs), block 256
+__global__ void __launch_bounds__(256) k_track_gather(const float* __restrict__ mag, size_t n, const unsigned* __restrict__ hist,
+                                                      SelState* __restrict__ sel, float* __restrict__ compact) {
+    __shared__ unsigned sh[3];
+    const size_t pair = blockIdx.y;
+    const unsigned* h = hist + pair * 2048;
+    const unsigned k = (unsigned)((n & 1u) ? n / 2 : n / 2 - 1);   // rank of the (lower) middle element
+    if (threadIdx.x < 64) {   // one wave: 32 bins per lane, wave scan (as in radix_select)
+        constexpr int per = 2048 / 64;
+        unsigned s = 0;
+        for (int i = 0; i < per; ++i) s += h[threadIdx.x * per + i];
+        unsigned incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += t;
+        }
+        const unsigned excl = incl - s;
+        if (k >= excl && k < incl) {
+            unsigned run = excl;
+            for (int i = 0; i < per; ++i) {
+                const unsigned c = h[threadIdx.x * per + i];
+                if (k < run + c) {
+                    sh[0] = threadIdx.x * per + i;
+                    sh[1] = run;
+                    sh[2] = c;
+                    break;
+                }
+                run += c;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned bin = sh[0];
+    SelState* st = sel + pair;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->bin = bin;
+        st->below = sh[1];
+        st->count = sh[2];
+    }
+    const float* x = mag + pair * n;
+    float* out = compact + pair * n;
+    // This workgroup's slice, in whole float4s.  Matches are staged in LDS (wave-aggregated append: one LDS atomic per
+    // wave and ballot) and flushed in blocks with ONE global atomic each -- a cursor bumped per wave would put tens of
+    // thousands of same-address atomics on every pair.
+    __shared__ float stage[GATHER_STAGE];
+    __shared__ unsigned cnt, gbase;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const size_t n4 = n / 4, per4 = (n4 + gridDim.x - 1) / gridDim.x, a4 = blockIdx.x * per4, b4 = min(n4, a4 + per4);
+    auto put = [&](float f) {
+        const bool m = (f == f) && ((__float_as_uint(f) >> 21) == (bin & 1023u)) && (bin >= 1024u) && !(__float_as_uint(f) & 0x80000000u);
+        const unsigned long long bal = __ballot(m);
+        if (bal == 0) return;
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&cnt, (unsigned)__popcll(bal));
+        base = __shfl(base, leader, 64);
+        if (m) stage[base + __popcll(bal & ((1ull << lane) - 1ull))] = f;
+    };
+    auto flush = [&]() {   // whole workgroup
+        __syncthreads();
+        const unsigned c = cnt;
+        if (threadIdx.x == 0) gbase = c ? atomicAdd(&st->fill, c) : 0u;
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < c; i += blockDim.x) out[gbase + i] = stage[i];
+        __syncthreads();
+        if (threadIdx.x == 0) cnt = 0;
+        __syncthreads();
+    };
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    // four 16-byte loads per lane in flight (the pass is a pure stream: with one load per lane it is latency-bound at
+    // ~3.8 TB/s); whole waves take part in every ballot; a round appends at most 4096 values, two rounds fill the stage
+    const float4 nan4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+    const size_t span = b4 > a4 ? b4 - a4 : 0, rounds = (span + 1023) / 1024;
+    for (size_t r = 0; r < rounds; ++r) {
+        if ((r & (GATHER_STAGE / 4096 - 1)) == 0 && r) flush();
+        const size_t i = a4 + r * 1024 + threadIdx.x;
+        float4 a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = i + 256 * k < b4 ? x4[i + 256 * k] : nan4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            put(a[k].x); put(a[k].y); put(a[k].z); put(a[k].w);
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1) {   // ragged tail of the map (n % 4 elements); the stage has room: see the flush rule
+        flush();
+        const size_t t0 = 4 * n4;
+        const float f = (t0 + threadIdx.x < n) ? x[t0 + threadIdx.x] : __builtin_nanf("");
+        if (threadIdx.x < 64) put(f);
+    }
+    flush();
+}
+
+// grid (pairs), block 1024, dynamic LDS FIN_LDS bytes
+__global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, const SelState* __restrict__ sel) {
+    constexpr int REP = FIN_REP;
+    extern __shared__ unsigned hist[];
+    __shared__ unsigned sh[4];
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const size_t pair = blockIdx.x;
+    const int mny = p.ny, mnx = p.nx, oy = p.ny / 2, ox = p.nx / 2;
+    const unsigned n = (unsigned)mny * mnx;
+    const float* mag = p.mag + pair * (size_t)n;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < p.nblk; i += blockDim.x)
+        argmax_merge(bv, bi, p.part_val[pair * p.nblk + i], p.part_idx[pair * p.nblk + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_down(bv, o, 64);
+        const int oi = __shfl_down(bi, o, 64);
+        argmax_merge(bv, bi, ov, oi);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sv[threadIdx.x >> 6] = bv;
+        si[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    bv = sv[0];
+    bi = si[0];
+    for (int i = 1; i < 16; ++i) argmax_merge(bv, bi, sv[i], si[i]);
+    __syncthreads();
+    // ---- median (np.median of a float32 map): passes 2-3 of the select on the gathered bin
+    const SelState ss = sel[pair];
+    const float* cx = p.compact + pair * (size_t)n;
+    const unsigned cn = ss.count;
+    unsigned nl, ne;
+    float med;
+    if (n & 1u) {
+        med = key2f(radix_select<REP>(cx, cn, n / 2, hist, sh, nl, ne, nullptr, nullptr, nullptr, 1, ss.bin << 21, ss.below));
+    } else {
+        const unsigned ka = radix_select<REP>(cx, cn, n / 2 - 1, hist, sh, nl, ne, nullptr, nullptr, nullptr, 1, ss.bin << 21, ss.below);
+        float a = key2f(ka), b = a;
+        if (nl + ne <= n / 2) {  // upper middle value = next larger element: in the gathered bin, else (rare) anywhere above it
+            unsigned kb = next_larger_key(cx, cn, ka, hist);
+            if (kb == 0xffffffffu) kb = next_larger_key(mag, n, ka, hist);
+            b = key2f(kb);
+        }
+        med = __fmul_rn(__fadd_rn(a, b), 0.5f);
+    }
+    if (threadIdx.x != 0) return;
+    track_finish(p, pair, mag, mny, mnx, oy, ox, bv, bi, med);
+}
+
+static int launch_track_fin2(const FinArgs& fa, const unsigned* hist, SelState* sel, int pairs, hipStream_t st) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_fin2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIN_LDS);
+    });
+    B4D_HIP(attr_err);
+    const size_t n = (size_t)fa.ny * fa.nx;
+    hipLaunchKernelGGL(k_track_gather, dim3(GATHER_SPLIT, pairs), dim3(256), 0, st, fa.mag, n, hist, sel, fa.compact);
+    hipLaunchKernelGGL(k_track_fin2, dim3(pairs), dim3(1024), FIN_LDS, st, fa, (const SelState*)sel);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
@@ -817,6 +992,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     add(sizeof(float) * fpix * pc);           // median scratch (gathered bin)
     add(sizeof(float) * 2048 * (size_t)pc);
     add(sizeof(int) * 2048 * (size_t)pc);
+    add(sizeof(unsigned) * (2048 + 4) * (size_t)pc);   // first-pass histograms + select state of the median
     Arena ar;
     int rc = track_arena(pl, need, &ar);
     if (rc) return rc;
@@ -832,6 +1008,8 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     float* medws = ar.take<float>(fpix * pc);
     float* pval = ar.take<float>((size_t)2048 * pc);
     int* pind = ar.take<int>((size_t)2048 * pc);
+    unsigned* mhist = ar.take<unsigned>((size_t)(2048 + 4) * pc);
+    SelState* msel = reinterpret_cast<SelState*>(mhist + (size_t)2048 * pc);
 
     // ---- source descriptors: images (full frame, z-scored), then templates (ROI, z-scored, zero elsewhere)
     std::vector<RowSrc> h(nsrc);
@@ -878,6 +1056,8 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         ra.ct_w = pl->ct_w;
         ra.part_val = pval;
         ra.part_idx = pind;
+        ra.hist = mhist;
+        B4D_HIP(hipMemsetAsync(mhist, 0, sizeof(unsigned) * (2048 + 4) * (size_t)pc, st));   // histograms and gather cursors
         int nblk = 0;
         if ((rc = dispatch_c2r(pl, ra, np, st, C2R_MAG, nullptr, &nblk))) return rc;
         FinArgs fa{};
@@ -892,7 +1072,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         fa.nblk = nblk;
         fa.subpixel = subpixel;
         fa.eps = eps;
-        if ((rc = launch_track_fin(fa, np, st))) return rc;
+        if ((rc = launch_track_fin2(fa, mhist, msel, np, st))) return rc;
         B4D_HIP(hipGetLastError());
     }
     return B4D_OK;

@@ -487,21 +487,16 @@ def speckle_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "al
     grid_slices, grid_labels = roi_grid_3x3((H, W), (roi_side, roi_side), (step, step), center_yx=None)
     rois = [(s[0].start, s[0].stop, s[1].start, s[1].stop) for s in grid_slices.ravel()]
 
-    # abs: frame-0 templates (9, shared by every t); inc: templates cut from frame t-1 (frame 0 for t = 0)
-    tpl_frame = [0] * 9 + [max(t - 1, 0) for t in range(T) for _ in range(9)]
-    tpl_roi = rois + rois * T
-    pair_img = [t for t in range(T) for _ in range(9)] * 2
-    pair_tpl = [k for _ in range(T) for k in range(9)] + [9 + 9 * t + k for t in range(T) for k in range(9)]
-    dev = dev_all
-    if method == "template":
-        res = template_matching_batch(dev, dev, tpl_frame, tpl_roi, pair_img, pair_tpl, backend=tracking_backend,
-                                      subpixel=subpixel, eps=1e-9)
-    else:
-        res = phase_correlation_batch(dev, dev, tpl_frame, tpl_roi, pair_img, pair_tpl, subpixel=subpixel, eps=1e-9)
-    dy_abs = res[:9 * T, 0].reshape(T, 3, 3).astype(np.float32)
-    dx_abs = res[:9 * T, 1].reshape(T, 3, 3).astype(np.float32)
-    dy_inc = res[9 * T:, 0].reshape(T, 3, 3).astype(np.float32)
-    dx_inc = res[9 * T:, 1].reshape(T, 3, 3).astype(np.float32)
+    # abs: frame-0 templates (9, shared by every t); inc: templates cut from frame t-1 (frame 0 for t = 0).  Frames go
+    # through the tracker in blocks (metrics/sharded.py: track_abs_inc) so that the resident spectra stay bounded.
+    from .sharded import track_abs_inc
+
+    res_abs, res_inc = track_abs_inc(dev_all, dev_all[0], dev_all[0], rois, method=method,
+                                     backend=tracking_backend if method == "template" else "internal", subpixel=subpixel, eps=1e-9)
+    dy_abs = res_abs[:, 0].reshape(T, 3, 3).astype(np.float32)
+    dx_abs = res_abs[:, 1].reshape(T, 3, 3).astype(np.float32)
+    dy_inc = res_inc[:, 0].reshape(T, 3, 3).astype(np.float32)
+    dx_inc = res_inc[:, 1].reshape(T, 3, 3).astype(np.float32)
 
     def block(dx, dy):
         r = np.sqrt(dx ** 2 + dy ** 2)

@@ -252,6 +252,17 @@ def test_sharded_tracking_equals_single_rank(gs):
     b = sharded.track_stack_sharded(stack[2:], rois, frame0=stack[0], prev=stack[1])
     for k in full:
         assert np.array_equal(np.concatenate([a[k], b[k]]), full[k]), k
+    # frames in blocks (bounded spectra workspace, metrics/sharded.py: track_abs_inc): a budget that fits ONE frame per
+    # call -- (1 image + 2 templates + 2 abs templates) half spectra of 256 KiB -- and one that fits two
+    for budget in (5 * 4 * 256 * 256, 8 * 4 * 256 * 256):
+        blk = sharded.track_stack_sharded(stack, rois, frame0=stack[0], prev=stack[0], workspace_bytes=budget)
+        for k in full:
+            assert np.array_equal(blk[k], full[k]), (budget, k)
+    tpl = sharded.track_stack_sharded(stack, rois, frame0=stack[0], prev=stack[0], method="template", backend="skimage")
+    tpl1 = sharded.track_stack_sharded(stack, rois, frame0=stack[0], prev=stack[0], method="template", backend="skimage",
+                                       workspace_bytes=9 * 4 * 256 * 256)
+    for k in tpl:
+        assert np.array_equal(tpl[k], tpl1[k]), k
     big = [(30, 151, 40, 161)]                                       # a well-conditioned ROI also recovers the ground truth
     tr = sharded.track_stack_sharded(stack, big, frame0=stack[0], prev=stack[0], subpixel=False)
     assert np.array_equal(tr["dy_abs"][:, 0], sh[:, 0]) and np.array_equal(tr["dx_abs"][:, 0], sh[:, 1])

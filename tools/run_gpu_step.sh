@@ -1,2 +1,4 @@
-mkdir -p gpurun_out/r2i
-timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py -x -q -m gpu -s > gpurun_out/r2i/pytest.log 2>&1; grep -n "observed\|passed\|failed\|Error\|assert" gpurun_out/r2i/pytest.log | head -20
+mkdir -p gpurun_out/r2j
+timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py tests/test_gpu_metrics.py tests/test_gpu_signal.py -x -q -m gpu > gpurun_out/r2j/pytest.log 2>&1; tail -5 gpurun_out/r2j/pytest.log
+timeout -k 10 300 python tools/bench_configs.py 3 2>&1 | tail -1
+bash tools/prof_stats.sh r2j/cfg3 tools/bench_configs.py 3 > /dev/null; python3 tools/prof_summary.py gpurun_out/r2j/cfg3 | head -12
