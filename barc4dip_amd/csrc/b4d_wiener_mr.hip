@@ -40,15 +40,29 @@ __host__ __device__ constexpr size_t wmr_rows_lds() {
     return sizeof(float2) * ((size_t)WMR_Q * MX::BUF + MX::M1) + sizeof(float) * (WMR_Q * MX::LANES / 64);
 }
 
-// quad q (over all frames of the launch) -> frame f, first pair 4 qi of the frame
+// Work index j -> quad.  Quads 2 m and 2 m + 1 of a frame share every 128-byte line of the transposed spectrum (their
+// 64-byte pieces are neighbours), and workgroup b of a launch runs on XCD b % 8: items j and j + 8 -- the same XCD, adjacent
+// dispatch slots -- are therefore mapped to such a pair, so that the two halves of a line meet in ONE L2 (measured before
+// this map: FETCH_SIZE of k_wmr_rows_inv 2.05 x its algorithmic bytes, WRITE_SIZE of k_wmr_rows_fwd 1.23 x).
+// Quads are numbered in a per-frame space padded to an even count (qpf2), items in groups of 16; invalid ones are skipped.
 struct QuadRef {
     int f, qi;
+    bool valid;
 };
+__device__ __forceinline__ QuadRef quad_of(int j, int qpf, int qpf2, int nframes) {
+    const int xcd = j & 7, r = j >> 3;
+    const int Q = ((r >> 1) << 4) + (xcd << 1) + (r & 1);
+    QuadRef q;
+    q.f = Q / qpf2;
+    q.qi = Q - q.f * qpf2;
+    q.valid = q.f < nframes && q.qi < qpf;
+    return q;
+}
 
 template <class MX>
 __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* __restrict__ frames, float2* __restrict__ T,
                                                                     const float2* __restrict__ twN, float* __restrict__ pmax, WmrGeom g,
-                                                                    int nquads, int qpf) {
+                                                                    int nframes, int qpf) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     constexpr int R1 = MX::R1, M1 = MX::M1, L = MX::LANES, RD = MX::ROUNDS1, N = MX::N, WG = WMR_Q * L;
     const int tid = threadIdx.x, lt = tid % L;
@@ -59,8 +73,14 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
     float2 v[RD][R1];
     float mx = 0.f;
     // frame loads of quad q for this lane's pair (compute mapping: lane lt of group sub owns items lt, lt + L, ...)
-    auto load = [&](int q, int lt, int sub) {
-        const int f = q / qpf, pr = WMR_Q * (q - f * qpf) + sub;
+    const int qpf2 = (qpf + 1) & ~1, nitems = (nframes * qpf2 + 15) & ~15;
+    auto next_item = [&](int j) {   // next work item of this workgroup that maps to a real quad (nitems if none)
+        for (j += gridDim.x; j < nitems && !quad_of(j, qpf, qpf2, nframes).valid; j += gridDim.x) {}
+        return j;
+    };
+    auto load = [&](int j, int lt, int sub) {
+        const QuadRef qr = quad_of(j, qpf, qpf2, nframes);
+        const int f = qr.f, pr = WMR_Q * qr.qi + sub;
         const bool act = pr < g.hp;
         const int r0 = 2 * (act ? pr : 0);
         const bool has_b = act && r0 + 1 < g.H;
@@ -89,8 +109,9 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
 #ifndef B4D_WMR_PREFETCH
 #define B4D_WMR_PREFETCH 1   // issue the next quad's global loads before the current quad's store loop (A/B: tools/dev_cfg5.py)
 #endif
-    if (B4D_WMR_PREFETCH && (int)blockIdx.x < nquads) load(blockIdx.x, (lt + 64 * (tid / L)) % L, tid / L);
-    for (int q = blockIdx.x; q < nquads; q += gridDim.x) {
+    int q = next_item((int)blockIdx.x - (int)gridDim.x);
+    if (B4D_WMR_PREFETCH && q < nitems) load(q, (lt + 64 * (tid / L)) % L, tid / L);
+    for (; q < nitems; q = next_item(q)) {
         // Everything derived from the lane index or the tables is invariant in q: left alone, the compiler precomputes all of
         // it (twiddle loads included) ahead of the quad loop and spills > 100 dwords around the radix stages.  Opaque
         // per-iteration copies keep those values short-lived.
@@ -100,7 +121,8 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
         const int subq = tidq / L;
         float2* bufq = sm + (size_t)subq * MX::BUF;
         const float2* tw2q = sm + (size_t)WMR_Q * MX::BUF;
-        const int f = q / qpf, qi = q - f * qpf, pr = WMR_Q * qi + subq;
+        const QuadRef qr = quad_of(q, qpf, qpf2, nframes);
+        const int f = qr.f, qi = qr.qi, pr = WMR_Q * qi + subq;
         const bool act = pr < g.hp;
         // The stages have M1 / M2 / M3 items for L lanes, so each leaves the group's last waves idle (radix 27: 152 items,
         // waves 2.4 .. 3).  Wave w of every group sits on SIMD w % 4: rotating the item <-> lane map by one wave per
@@ -126,7 +148,10 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
         __syncthreads();
         MX::stage3(bufq, ltr);
         __syncthreads();
-        if (B4D_WMR_PREFETCH && q + (int)gridDim.x < nquads) load(q + gridDim.x, ltr, subq);   // in flight under the store loop
+        {
+            const int qn = next_item(q);
+            if (B4D_WMR_PREFETCH && qn < nitems) load(qn, ltr, subq);   // in flight under the store loop
+        }
         // piece mapping: lanes 4 i .. 4 i + 3 hold the four pairs' pieces of ONE k: 64 contiguous bytes of T[k][.]
         const int j = tidq & (WMR_Q - 1), kk = tidq / WMR_Q;
         const float2* bj = sm + (size_t)j * MX::BUF;
@@ -224,7 +249,7 @@ __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ 
 template <class MX>
 __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_inv(const float2* __restrict__ T, float* __restrict__ out,
                                                                     const float2* __restrict__ twN, const float* __restrict__ amax, WmrGeom g,
-                                                                    int nquads, int qpf) {
+                                                                    int nframes, int qpf) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     constexpr int R1 = MX::R1, M1 = MX::M1, L = MX::LANES, RD = MX::ROUNDS1, N = MX::N, WG = WMR_Q * L;
     const int tid = threadIdx.x, lt = tid % L;
@@ -233,21 +258,29 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_inv(const float2*
     // the 16-byte pieces of quad q this lane gathers (piece mapping: k = tid / 4 + i L, pair tid % 4), clamped addresses
     constexpr int NP = (N / 2 + 1 + L - 1) / L;
     float4 pc[NP];
-    auto fetch = [&](int q, int tidq) {
-        const int f = q / qpf, pj = WMR_Q * (q - f * qpf) + (tidq & (WMR_Q - 1)), kk = tidq / WMR_Q;
+    const int qpf2 = (qpf + 1) & ~1, nitems = (nframes * qpf2 + 15) & ~15;
+    auto next_item = [&](int j) {
+        for (j += gridDim.x; j < nitems && !quad_of(j, qpf, qpf2, nframes).valid; j += gridDim.x) {}
+        return j;
+    };
+    auto fetch = [&](int j, int tidq) {
+        const QuadRef qr = quad_of(j, qpf, qpf2, nframes);
+        const int f = qr.f, pj = WMR_Q * qr.qi + (tidq & (WMR_Q - 1)), kk = tidq / WMR_Q;
         const float2* src = T + (size_t)f * g.Wh * g.Hp + 2 * min(pj, g.hp - 1);
 #pragma unroll
         for (int i = 0; i < NP; ++i) pc[i] = *reinterpret_cast<const float4*>(src + (size_t)min(kk + i * L, g.Wh - 1) * g.Hp);
     };
-    if (B4D_WMR_PREFETCH && (int)blockIdx.x < nquads) fetch(blockIdx.x, tid);
-    for (int q = blockIdx.x; q < nquads; q += gridDim.x) {
+    int q = next_item((int)blockIdx.x - (int)gridDim.x);
+    if (B4D_WMR_PREFETCH && q < nitems) fetch(q, tid);
+    for (; q < nitems; q = next_item(q)) {
         int ltq = lt, tidq = tid;   // opaque per-iteration copies (see k_wmr_rows_fwd)
         const float2* twq = twN;
         asm volatile("" : "+v"(ltq), "+v"(tidq), "+s"(twq));
         const int subq = tidq / L;
         float2* bufq = sm + (size_t)subq * MX::BUF;
         const float2* tw2q = sm + (size_t)WMR_Q * MX::BUF;
-        const int f = q / qpf, qi = q - f * qpf, pr = WMR_Q * qi + subq;
+        const QuadRef qr = quad_of(q, qpf, qpf2, nframes);
+        const int f = qr.f, qi = qr.qi, pr = WMR_Q * qi + subq;
         {   // piece mapping: four neighbouring lanes gather the four pairs' 16-byte pieces of ONE k (a 64-byte sector);
             // Ga + i Gb, Hermitian-extended beyond N/2, conjugated for the inverse, lands in natural order in the pair's buffer
             const int j = tidq & (WMR_Q - 1), kk = tidq / WMR_Q, pj = WMR_Q * qi + j;
@@ -294,7 +327,10 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_inv(const float2*
         const bool act = pr < g.hp;
         const bool wa = act && ya >= 0 && ya < g.h, wb = act && r0 + 1 < g.H && yb >= 0 && yb < g.h;
         float* orow = out + ((size_t)f * g.h + ya) * g.w;
-        if (B4D_WMR_PREFETCH && q + (int)gridDim.x < nquads) fetch(q + gridDim.x, tidq);   // in flight under the store loop
+        {
+            const int qn = next_item(q);
+            if (B4D_WMR_PREFETCH && qn < nitems) fetch(qn, tidq);   // in flight under the store loop
+        }
         typename MX::template PosIter<L> pk(ltq + g.px);
         for (int x = ltq; x < g.w; x += L) {
             const float2 z = bufq[pk.pos()];
@@ -359,7 +395,7 @@ int wmr_rows_fwd(const float* frames, float2* T, const float2* twx, float* pmax,
     case N_: {                                                                                                                             \
         using MX = Mix3<A_, B_, C_, L_>;                                                                                                   \
         if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_fwd<MX>, nquads, st, &lds, &grid))) return rc;                                          \
-        hipLaunchKernelGGL((k_wmr_rows_fwd<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, frames, T, twx, pmax, g, nquads, qpf);              \
+        hipLaunchKernelGGL((k_wmr_rows_fwd<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, frames, T, twx, pmax, g, nframes, qpf);              \
     } break;
         B4D_WMR_LENGTHS(X)
 #undef X
@@ -394,7 +430,7 @@ int wmr_rows_inv(const float2* T, float* out, const float2* twx, const float* am
     case N_: {                                                                                                                             \
         using MX = Mix3<A_, B_, C_, L_>;                                                                                                   \
         if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_inv<MX>, nquads, st, &lds, &grid))) return rc;                                          \
-        hipLaunchKernelGGL((k_wmr_rows_inv<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, T, out, twx, amax, g, nquads, qpf);                 \
+        hipLaunchKernelGGL((k_wmr_rows_inv<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, T, out, twx, amax, g, nframes, qpf);                 \
     } break;
         B4D_WMR_LENGTHS(X)
 #undef X
