@@ -171,8 +171,10 @@ def default_chunk(ny: int, nx: int) -> int:
     multiples of 256 column tiles to amortise its ragged tail: aim at >= 4096 tiles per launch
     (measured on MI355X at 2048^2: chunk 6 -> 21k frames/s, 32 -> 34k, 64 -> 36k), workspace <= 1 GiB."""
     pow2 = lambda n: 64 <= n <= 4096 and n & (n - 1) == 0  # noqa: E731
-    if not (pow2(ny) and pow2(nx)):   # general-length plan: three complex chunk buffers, <= 1 GiB in total
-        return max(1, min(128, (1024 << 20) // (24 * ny * nx)))
+    if not (pow2(ny) and pow2(nx)):   # general-length plan: three complex chunk buffers, <= 1 GiB in total (2 GiB for
+        # detector-sized frames: the persistent row kernels of the mixed-radix route want >= 16 frames per launch)
+        budget = (2048 << 20) if max(ny, nx) > 1024 else (1024 << 20)
+        return max(1, min(128, budget // (24 * ny * nx)))
     ct = 8 if ny == 4096 else 16
     tiles = max(1, (nx // 2) // ct)
     chunk = -(-4096 // tiles)

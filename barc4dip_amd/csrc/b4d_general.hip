@@ -9,6 +9,7 @@
 // The product kernel is a plain LDS-tiled complex GEMM on the vector ALUs (64x64 tile, 4x4 register block);
 // moving it to v_mfma_f32_32x32x2_f32 is listed in DESIGN.md §8.
 #include "b4d_fft2d.hpp"
+#include "b4d_wiener_mr.hpp"
 
 namespace b4d {
 
@@ -322,6 +323,20 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
                          unsigned flags, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
     const dim3 eg((npix + 255) / 256, 1);
+    if (pl->large && wmr_supported(nx) && wmr_supported(ny)) {
+        // both sides have in-register three-radix kernels (b4d_wiener_mr.hip): forward row pairs -> transposed half spectra,
+        // one pass over the columns (forward, |F|^2, inverse; the column stays in LDS), inverse row pairs + PSD rows:
+        // 3 passes and ~32 bytes per pixel where the route below makes 7 passes
+        for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
+            const int nb = std::min(pl->chunk, batch - b0);
+            const size_t off = (size_t)b0 * npix;
+            int rc = wmr_psd_autocorr(frames + off, nb, ny, nx, pl->tw_x, pl->tw_y, pl->gbuf1, reinterpret_cast<float*>(pl->gbuf2),
+                                      reinterpret_cast<float*>(pl->gbuf3), psd ? psd + off : nullptr, psd_scale,
+                                      autocorr ? autocorr + off : nullptr, flags, st);
+            if (rc) return rc;
+        }
+        return B4D_OK;
+    }
     if (pl->large && pm_fusable(nx) && pm_fusable(ny)) {
         // half-spectrum path: pair rows -> transpose -> columns on nx/2 + 1 sequences -> |F|^2 (+ PSD) -> inverse columns ->
         // transpose -> Hermitian pair rows written fftshift-ed and normalised: ~56 instead of ~148 bytes per pixel

@@ -1202,7 +1202,7 @@ int b4d_wiener_create(int h, int w, const float* psf_host, int ky, int kx, float
         WmrGeom& g = p->geom;
         g.h = h, g.w = w, g.py = p->py, g.px = p->px, g.H = p->H, g.W = p->W;
         g.Wh = p->W / 2 + 1;
-        g.Hp = (p->H + 1 + 15) / 16 * 16;
+        g.Hp = wmr_pitch(p->H);
         g.hp = (p->H + 1) / 2;
         g.clip = 0;
         g.inv = 1.0f / ((float)p->H * (float)p->W);

@@ -170,10 +170,15 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
     }
 }
 
-template <class MY>
+// MODE 0: times the Wiener filter `filt` (deconvolve_psf).  MODE 1 (fft -> psd -> autocorr at general sizes,
+// signal/fft.py:261-309 + signal/corr.py:256-320): P = |F|^2 (DC zeroed when flags & B4D_REMOVE_MEAN) replaces the product,
+// is stored as a REAL column to Pt (same [k][ky] layout, pitch g.Hp floats) when Pt != null, and is what the inverse
+// transform runs on (skipped when `inverse` == 0: PSD only).
+template <class MY, int MODE>
 __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ T, const float2* __restrict__ filt,
                                                             const float2* __restrict__ twN, const float* __restrict__ pmax,
-                                                            float* __restrict__ amax, WmrGeom g) {
+                                                            float* __restrict__ amax, WmrGeom g, float* __restrict__ Pt, unsigned flags,
+                                                            int inverse) {
     __shared__ __attribute__((aligned(16))) float2 buf[MY::BUF];
     __shared__ float2 tw2[MY::M1];
     constexpr int R1 = MY::R1, M1 = MY::M1, LANES = MY::LANES, RD = MY::ROUNDS1, N = MY::N;
@@ -181,9 +186,9 @@ __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ 
     const int col = blockIdx.x;
     const int f = col / g.Wh, k = col - f * g.Wh;
     float2* x = T + (size_t)col * g.Hp;
-    const float2* fl = filt + (size_t)k * g.Hp;
+    const float2* fl = MODE == 0 ? filt + (size_t)k * g.Hp : nullptr;
     MY::build_tw2(tw2, twN, tid);
-    if (k == 0 && tid < 64) {   // max|frame| from the pair maxima of k_wmr_rows_fwd (fmaxf drops NaN: np.nanmax)
+    if (MODE == 0 && k == 0 && tid < 64) {   // max|frame| from the pair maxima of k_wmr_rows_fwd (fmaxf drops NaN: np.nanmax)
         float mx = 0.f;
         for (int i = tid; i < g.hp; i += 64) mx = fmaxf(mx, pmax[(size_t)f * g.hp + i]);
 #pragma unroll
@@ -204,11 +209,13 @@ __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ 
     }
     // the filter values of the second transform's inputs: in flight under the first transform
     float2 fv[RD][R1];
+    if (MODE == 0) {
 #pragma unroll
-    for (int r = 0; r < RD; ++r) {
-        const int mc = min(tid + r * LANES, M1 - 1);
+        for (int r = 0; r < RD; ++r) {
+            const int mc = min(tid + r * LANES, M1 - 1);
 #pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) fv[r][n1] = fl[M1 * n1 + mc];
+            for (int n1 = 0; n1 < R1; ++n1) fv[r][n1] = fl[M1 * n1 + mc];
+        }
     }
     __syncthreads();
     MY::stage2(buf, tw2, tid);
@@ -222,11 +229,21 @@ __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ 
         typename MY::template PosIter<M1> pi(mc);   // n = mc, mc + M1, ...
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
-            const float2 p = cmul(buf[pi.pos()], fv[r][n1]);
-            v[r][n1] = make_float2(p.x, -p.y);
+            if (MODE == 0) {
+                const float2 p = cmul(buf[pi.pos()], fv[r][n1]);
+                v[r][n1] = make_float2(p.x, -p.y);
+            } else {
+                const float2 f = buf[pi.pos()];
+                const int n = M1 * n1 + mc;
+                float p = f.x * f.x + f.y * f.y;
+                if (Pt && tid + r * LANES < M1) Pt[(size_t)col * g.Hp + n] = p;   // raw power: the scale is applied by the row pass
+                if (n == 0 && k == 0 && (flags & B4D_REMOVE_MEAN)) p = 0.f;       // mean removal = DC bin of the power spectrum
+                v[r][n1] = make_float2(p, 0.f);
+            }
             pi.up();
         }
     }
+    if (MODE == 1 && !inverse) return;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RD; ++r) {
@@ -347,10 +364,148 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_inv(const float2*
     }
 }
 
+// Zero-lag value of the (unscaled) autocorrelation of every frame from the column-inverted half spectrum G = T[k][y]:
+// R[0,0] = sum over the FULL kx range of G[kx][0] = G[0] + 2 sum Re G[k] (+ G[W/2] for even W).  grid (nframes), block 256
+__global__ void __launch_bounds__(256) k_wmr_peak(const float2* __restrict__ T, WmrGeom g, float* __restrict__ peak) {
+    __shared__ double sh[4];
+    const float2* t = T + (size_t)blockIdx.x * g.Wh * g.Hp;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < g.Wh; k += 256) {
+        const double v = (double)t[(size_t)k * g.Hp].x;
+        acc += (k == 0 || 2 * k == g.W) ? v : 2.0 * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) peak[blockIdx.x] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// Last pass of fft -> psd -> autocorr at general sizes.  Same quads, piece gathers and transforms as k_wmr_rows_inv; the
+// epilogue writes the two real rows of every pair fftshift-ed in both axes, scaled by 1/(H W) or, with B4D_NORM_PEAK and a
+// positive zero-lag value peak[f], divided by it with the zero lag forced to exactly 1 (signal/corr.py:247-250).  When
+// psd != null the quad first turns its 8 rows ky of the transposed power spectrum Pt into PSD rows: 8-byte pieces of four
+// neighbouring lanes (32 bytes) staged through the row buffers, then every pair writes its two rows along kx -- the direct
+// half (ky, kx) and the Hermitian mirror (-ky, -kx), both fftshift-ed (signal/fft.py:300-309).
+template <class MX>
+__global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_out(const float2* __restrict__ T, const float* __restrict__ Pt,
+                                                                    float* __restrict__ autocorr, float* __restrict__ psd,
+                                                                    const float2* __restrict__ twN, const float* __restrict__ peak, WmrGeom g,
+                                                                    int nframes, int qpf, float psd_scale, unsigned flags) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr int R1 = MX::R1, M1 = MX::M1, L = MX::LANES, RD = MX::ROUNDS1, N = MX::N, WG = WMR_Q * L;
+    const int tid = threadIdx.x, lt = tid % L;
+    float2* tw2 = sm + (size_t)WMR_Q * MX::BUF;
+    for (int t = tid; t < M1; t += WG) tw2[t] = twN[R1 * t];
+    const int qpf2 = (qpf + 1) & ~1, nitems = (nframes * qpf2 + 15) & ~15;
+    auto next_item = [&](int j) {
+        for (j += gridDim.x; j < nitems && !quad_of(j, qpf, qpf2, nframes).valid; j += gridDim.x) {}
+        return j;
+    };
+    const size_t fpix = (size_t)g.H * g.W;
+    for (int q = next_item((int)blockIdx.x - (int)gridDim.x); q < nitems; q = next_item(q)) {
+        int ltq = lt, tidq = tid;   // opaque per-iteration copies (see k_wmr_rows_fwd)
+        const float2* twq = twN;
+        asm volatile("" : "+v"(ltq), "+v"(tidq), "+s"(twq));
+        const int subq = tidq / L;
+        float2* bufq = sm + (size_t)subq * MX::BUF;
+        const float2* tw2q = sm + (size_t)WMR_Q * MX::BUF;
+        const QuadRef qr = quad_of(q, qpf, qpf2, nframes);
+        const int f = qr.f, qi = qr.qi, pr = WMR_Q * qi + subq;
+        const bool act = pr < g.hp;
+        const int r0 = 2 * pr;
+        const bool has_b = act && r0 + 1 < g.H;
+        const int j = tidq & (WMR_Q - 1), kk = tidq / WMR_Q, pj = WMR_Q * qi + j;
+        if (psd) {
+            // ---- PSD rows ky = r0, r0 + 1 of every pair: gather (piece mapping) -> stage -> two half rows along kx
+            float* stg = reinterpret_cast<float*>(sm + (size_t)j * MX::BUF);   // pair j: [row a | row b], g.Wh floats each
+            const float* src = Pt + (size_t)f * g.Wh * g.Hp + 2 * min(pj, g.hp - 1);
+            for (int k = kk; k < g.Wh; k += L) {
+                const float2 p = *reinterpret_cast<const float2*>(src + (size_t)k * g.Hp);
+                stg[k] = p.x;
+                stg[g.Wh + k] = p.y;
+            }
+            __syncthreads();
+            const float* mine = reinterpret_cast<const float*>(bufq);
+            float* pf = psd + (size_t)f * fpix;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ky = r0 + e;
+                if (!act || ky >= g.H) continue;
+                float* drow = pf + (size_t)((ky + g.H / 2) % g.H) * g.W;                      // direct half: (ky, kx)
+                float* mrow = pf + (size_t)(((g.H - ky) % g.H + g.H / 2) % g.H) * g.W;        // mirror: (-ky, -kx)
+                const float* prow = mine + e * g.Wh;
+                for (int kx = ltq; kx < g.Wh; kx += L) {
+                    const float v = prow[kx] * psd_scale;
+                    drow[(kx + g.W / 2) % g.W] = v;
+                    if (kx > 0 && 2 * kx != g.W) mrow[(g.W - kx + g.W / 2) % g.W] = v;
+                }
+            }
+            __syncthreads();
+        }
+        if (!autocorr) continue;
+        {   // ---- inverse row transforms: piece gathers of G, Hermitian extension, conjugated for the inverse
+            float2* bj = sm + (size_t)j * MX::BUF;
+            const bool hb = 2 * pj + 1 < g.H;
+            const float2* src = T + (size_t)f * g.Wh * g.Hp + 2 * min(pj, g.hp - 1);
+            for (int k = kk; k < g.Wh; k += L) {
+                const float4 p = *reinterpret_cast<const float4*>(src + (size_t)k * g.Hp);
+                const float bx = hb ? p.z : 0.f, by = hb ? p.w : 0.f;
+                bj[k] = make_float2(p.x - by, -(p.y + bx));
+                if (k != 0 && 2 * k != N) bj[N - k] = make_float2(p.x + by, p.y - bx);
+            }
+        }
+        __syncthreads();
+        const int ltr = (ltq + 64 * subq) % L;
+        float2 v[RD][R1];
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+            const int mc = min(ltr + r * L, M1 - 1);
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) v[r][n1] = bufq[M1 * n1 + mc];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+            const int m = ltr + r * L;
+            if (m < M1) MX::stage1_item(v[r], m, bufq, twq);
+        }
+        __syncthreads();
+        MX::stage2(bufq, tw2q, ltr);
+        __syncthreads();
+        MX::stage3(bufq, ltr);
+        __syncthreads();
+        const float pk = (flags & B4D_NORM_PEAK) ? peak[f] : 0.f;
+        const bool unit = (flags & B4D_NORM_PEAK) && pk > 0.f;
+        const float se = unit ? 1.0f / pk : g.inv;
+        float* af = autocorr + (size_t)f * fpix;
+        float* rowa = af + (size_t)((r0 + g.H / 2) % g.H) * g.W;
+        float* rowb = af + (size_t)((r0 + 1 + g.H / 2) % g.H) * g.W;
+        typename MX::template PosIter<L> pk_it(ltq);
+        for (int x = ltq; x < g.W; x += L) {
+            const float2 z = bufq[pk_it.pos()];
+            pk_it.up();
+            float va = z.x * se;
+            const float vb = -z.y * se;   // conj(buf): real part row a, imaginary part row b
+            if (unit && r0 == 0 && x == 0) va = 1.0f;
+            const int c = (x + g.W / 2) % g.W;
+            if (act) rowa[c] = va;
+            if (has_b) rowb[c] = vb;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- instantiated lengths -----------------------------------------------------------------------------------------
-//   4104 = 4096 + 8 (sigma 1.5 on 4k frames), 520 = 512 + 8, 264 = 256 + 8
+//   4104 = 4096 + 8 (sigma 1.5 on 4k frames), 520 = 512 + 8, 264 = 256 + 8: Wiener padded sizes;
+//   2560 x 2160 (sCMOS), 1280 x 720, 600: general-size fft -> psd -> autocorr (b4d_general.hip)
 #define B4D_WMR_LENGTHS(X)       \
     X(4104, 8, 27, 19, 256)      \
+    X(2560, 16, 16, 10, 256)     \
+    X(2160, 16, 27, 5, 256)      \
+    X(1280, 16, 16, 5, 128)      \
+    X(720, 16, 9, 5, 64)         \
+    X(600, 8, 15, 5, 64)         \
     X(520, 8, 5, 13, 128)        \
     X(264, 8, 3, 11, 64)
 
@@ -405,17 +560,62 @@ int wmr_rows_fwd(const float* frames, float2* T, const float2* twx, float* pmax,
     return B4D_OK;
 }
 
-int wmr_cols(float2* T, const float2* filt, const float2* twy, const float* pmax, float* amax, const WmrGeom& g, int nframes,
-             hipStream_t st) {
+template <int MODE>
+static int wmr_cols_launch(float2* T, const float2* filt, const float2* twy, const float* pmax, float* amax, const WmrGeom& g,
+                           int nframes, float* Pt, unsigned flags, int inverse, hipStream_t st) {
     const unsigned grid = (unsigned)nframes * (unsigned)g.Wh;
     switch (g.H) {
-#define X(N_, A_, B_, C_, L_)                                                                                                  \
-    case N_:                                                                                                                   \
-        hipLaunchKernelGGL((k_wmr_cols<Mix3<A_, B_, C_, L_>>), dim3(grid), dim3(L_), 0, st, T, filt, twy, pmax, amax, g);      \
+#define X(N_, A_, B_, C_, L_)                                                                                                            \
+    case N_:                                                                                                                             \
+        hipLaunchKernelGGL((k_wmr_cols<Mix3<A_, B_, C_, L_>, MODE>), dim3(grid), dim3(L_), 0, st, T, filt, twy, pmax, amax, g, Pt, flags, \
+                           inverse);                                                                                                     \
         break;
         B4D_WMR_LENGTHS(X)
 #undef X
         default: return fail(B4D_ESIZE, "no mixed-radix column kernel for this length");
+    }
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int wmr_cols(float2* T, const float2* filt, const float2* twy, const float* pmax, float* amax, const WmrGeom& g, int nframes,
+             hipStream_t st) {
+    return wmr_cols_launch<0>(T, filt, twy, pmax, amax, g, nframes, nullptr, 0u, 1, st);
+}
+
+int wmr_psd_autocorr(const float* frames, int nframes, int ny, int nx, const float2* twx, const float2* twy, float2* T, float* Pt,
+                     float* scratch, float* psd, float psd_scale, float* autocorr, unsigned flags, hipStream_t st) {
+    WmrGeom g{};
+    g.h = g.H = ny;
+    g.w = g.W = nx;
+    g.py = g.px = 0;
+    g.Wh = nx / 2 + 1;
+    g.Hp = wmr_pitch(ny);
+    g.hp = (ny + 1) / 2;
+    g.inv = 1.0f / ((float)ny * (float)nx);
+    float* pmax = scratch;                       // (nframes, hp): by-product of the shared forward row kernel, unused here
+    float* peak = scratch + (size_t)nframes * g.hp;
+    int rc;
+    if ((rc = wmr_rows_fwd(frames, T, twx, pmax, g, nframes, st))) return rc;
+    if ((rc = wmr_cols_launch<1>(T, nullptr, twy, nullptr, nullptr, g, nframes, psd ? Pt : nullptr, flags, autocorr ? 1 : 0, st))) return rc;
+    if (autocorr && (flags & B4D_NORM_PEAK)) {
+        hipLaunchKernelGGL(k_wmr_peak, dim3(nframes), dim3(256), 0, st, (const float2*)T, g, peak);
+        B4D_HIP(hipGetLastError());
+    }
+    const int qpf = (g.hp + WMR_Q - 1) / WMR_Q, nquads = nframes * qpf;
+    size_t lds = 0;
+    int grid = 0;
+    switch (g.W) {
+#define X(N_, A_, B_, C_, L_)                                                                                                             \
+    case N_: {                                                                                                                            \
+        using MX = Mix3<A_, B_, C_, L_>;                                                                                                  \
+        if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_out<MX>, nquads, st, &lds, &grid))) return rc;                                         \
+        hipLaunchKernelGGL((k_wmr_rows_out<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, (const float2*)T, (const float*)Pt, autocorr, psd, \
+                           twx, (const float*)peak, g, nframes, qpf, psd_scale, flags);                                                   \
+    } break;
+        B4D_WMR_LENGTHS(X)
+#undef X
+        default: return fail(B4D_ESIZE, "no mixed-radix row kernel for this length");
     }
     B4D_HIP(hipGetLastError());
     return B4D_OK;

@@ -16,6 +16,14 @@ struct WmrGeom {
 
 // the length has a compiled three-radix kernel
 bool wmr_supported(int n);
+// pitch (complex / float words) of one column of the transposed workspaces for column length H
+inline int wmr_pitch(int H) { return (H + 1 + 15) / 16 * 16; }
+// fft -> psd -> autocorr of real (nframes, ny, nx) frames in three passes + a zero-lag reduction (general sizes whose sides
+// both have compiled kernels): T (nframes, nx/2 + 1, wmr_pitch(ny)) complex and Pt (same shape, float) are workspaces,
+// scratch holds nframes * ((ny + 1) / 2 + 1) floats.  psd / autocorr: (nframes, ny, nx) float32, fftshift-ed, either may be
+// null; flags: B4D_REMOVE_MEAN, B4D_NORM_PEAK.  signal/fft.py:261-309, signal/corr.py:256-320.
+int wmr_psd_autocorr(const float* frames, int nframes, int ny, int nx, const float2* twx, const float2* twy, float2* T, float* Pt,
+                     float* scratch, float* psd, float psd_scale, float* autocorr, unsigned flags, hipStream_t st);
 // frames (nframes, h, w) -> T (nframes, Wh, Hp) transposed half spectra; pmax (nframes, hp) = max|rows of each pair|
 int wmr_rows_fwd(const float* frames, float2* T, const float2* twx, float* pmax, const WmrGeom& g, int nframes, hipStream_t st);
 // every column of T: forward transform, times filt (Wh, Hp), inverse transform (unscaled), in place;
