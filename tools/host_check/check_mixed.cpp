@@ -103,6 +103,7 @@ int main() {
     worst = std::max(worst, check_mix<Mix3<8, 5, 13, 256>>());
     worst = std::max(worst, check_mix<Mix3<8, 3, 11, 128>>());
     worst = std::max(worst, check_mix<Mix3<16, 27, 5, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 16, 10, 256>>());
     printf(worst < 2e-6 ? "OK\n" : "FAIL\n");
     return worst < 2e-6 ? 0 : 1;
 }

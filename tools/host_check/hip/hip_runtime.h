@@ -11,3 +11,5 @@ struct float2 { float x, y; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline void __syncthreads() {}
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+static inline int min(int a, int b) { return a < b ? a : b; }
