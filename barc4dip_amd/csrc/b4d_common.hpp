@@ -15,10 +15,11 @@ inline int fail(int code, const std::string& msg) {
     last_error() = msg;
     return code;
 }
-// lazily grown device scratch for second-stage reductions (b4d_stats.hip)
-int get_scratch(size_t bytes, void** out);
-// serialises the host side of every entry point that works in that shared scratch (re-entrant calls from several
-// host threads, e.g. joblib workers); device-side ordering comes from the stream: use ONE stream for these calls
+// lazily grown device scratch for second-stage reductions (b4d_stats.hip), one buffer per caller stream
+int get_scratch(size_t bytes, void** out, hipStream_t stream);
+// serialises the host side of every entry point that works in a scratch buffer (re-entrant calls from several host
+// threads, e.g. joblib workers, on one stream); device-side ordering comes from the stream, and different streams get
+// different buffers
 std::recursive_mutex& scratch_mutex();
 #define B4D_SCRATCH_LOCK() std::lock_guard<std::recursive_mutex> b4d_scratch_lk__(::b4d::scratch_mutex())
 

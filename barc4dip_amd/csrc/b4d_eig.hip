@@ -514,7 +514,7 @@ extern "C" int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int 
         const size_t oJ = tk(sizeof(float) * npix * batch), oG = tk(sizeof(float) * (size_t)m * m * batch);
         const size_t oP = tk(sizeof(double) * (size_t)nblk * 3 * batch), oE = tk(sizeof(double) * 8 * batch), oS = tk(sizeof(double) * 3 * batch);
         void* ws = nullptr;
-        int rc = get_scratch(sb, &ws);
+        int rc = get_scratch(sb, &ws, (hipStream_t)stream);
         if (rc) return rc;
         char* base = static_cast<char*>(ws);
         float* J = reinterpret_cast<float*>(base + oJ);
@@ -562,7 +562,7 @@ extern "C" int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int 
     const size_t oP = take(sizeof(double) * part_elems), oP2 = take(sizeof(double) * part_elems);
     const size_t oR = take(sizeof(float) * NB * NB * batch), oE = take(sizeof(double) * 8 * batch), oS = take(sizeof(double) * 3 * batch);
     void* ws = nullptr;
-    int rc = get_scratch(bytes, &ws);
+    int rc = get_scratch(bytes, &ws, (hipStream_t)stream);
     if (rc) return rc;
     char* base = static_cast<char*>(ws);
     float* J = reinterpret_cast<float*>(base + oJ);

@@ -133,7 +133,7 @@ extern "C" int b4d_repair_pixels(float* frames, int batch, int ny, int nx, const
     if (nbad == 0) return B4D_OK;
     hipStream_t st = (hipStream_t)stream;
     void* ws = nullptr;
-    int rc = get_scratch(sizeof(float) * (size_t)batch * nbad, &ws);
+    int rc = get_scratch(sizeof(float) * (size_t)batch * nbad, &ws, (hipStream_t)stream);
     if (rc) return rc;
     float* rep = static_cast<float*>(ws);
     hipLaunchKernelGGL(k_bad_median, dim3((nbad + 255) / 256, batch), dim3(256), 0, st, frames, ny, nx, idx, nbad, rep);

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/b4d.h"
 #include "b4d_common.hpp"
@@ -22,24 +23,30 @@ namespace b4d {
 // Lazily grown per-process device scratch for second-stage reductions (never reallocated on the
 // hot path once it has reached its high-water mark).
 static std::mutex g_scratch_mu;
-static void* g_scratch = nullptr;
-static size_t g_scratch_bytes = 0;
+struct StreamScratch {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+static std::unordered_map<hipStream_t, StreamScratch> g_stream_scratch;   // one lazily grown buffer per caller stream
 std::recursive_mutex& scratch_mutex() {
     static std::recursive_mutex m;
     return m;
 }
-int get_scratch(size_t bytes, void** out) {
+// One buffer per stream: the kernels of these entry points are asynchronous, so two streams sharing one scratch would
+// race on the device however well the host side is locked (the plans and the Wiener plan cache are per stream too).
+int get_scratch(size_t bytes, void** out, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    if (bytes > g_scratch_bytes) {
-        if (g_scratch) (void)hipFree(g_scratch);
-        g_scratch = nullptr;
-        g_scratch_bytes = 0;
+    StreamScratch& sc = g_stream_scratch[stream];
+    if (bytes > sc.bytes) {
+        if (sc.p) (void)hipFree(sc.p);   // hipFree waits for the work that still uses the old buffer
+        sc.p = nullptr;
+        sc.bytes = 0;
         const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-        hipError_t e = hipMalloc(&g_scratch, want);
+        hipError_t e = hipMalloc(&sc.p, want);
         if (e != hipSuccess) return fail(B4D_ENOMEM, std::string("scratch allocation: ") + hipGetErrorString(e));
-        g_scratch_bytes = want;
+        sc.bytes = want;
     }
-    *out = g_scratch;
+    *out = sc.p;
     return B4D_OK;
 }
 
@@ -833,7 +840,7 @@ int b4d_moments(const float* frames, int batch, size_t npix, double eps, double 
     const size_t work = (npix / 4 + 1023) / 1024;
     if ((size_t)split > work) split = (int)(work ? work : 1);
     void* ws = nullptr;
-    int rc = get_scratch(sizeof(double) * 7 * (size_t)batch * split, &ws);
+    int rc = get_scratch(sizeof(double) * 7 * (size_t)batch * split, &ws, (hipStream_t)stream);
     if (rc) return rc;
     double* p1 = static_cast<double*>(ws);
     double* p2 = p1 + (size_t)4 * batch * split;
@@ -852,7 +859,7 @@ int b4d_sobel_laplace_stats(const float* frames, int batch, int ny, int nx, doub
     const dim3 grid((nx + 63) / 64, (ny + 15) / 16, batch);
     const int nblk = grid.x * grid.y;
     void* ws = nullptr;
-    int rc = get_scratch(sizeof(double) * 5 * (size_t)batch * nblk, &ws);
+    int rc = get_scratch(sizeof(double) * 5 * (size_t)batch * nblk, &ws, (hipStream_t)stream);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sobel_lap, grid, dim3(64, 4), 0, st, frames, ny, nx, static_cast<double*>(ws));
@@ -872,7 +879,7 @@ int b4d_percentiles(const float* frames, int batch, size_t npix, const double* q
     const bool multi = npix >= ((size_t)1 << 17);
     const size_t hist_words = multi ? (size_t)batch * nq * 2048 : 0, state_words = multi ? (size_t)batch * nq * 8 : 0;
     void* ws = nullptr;
-    int rc = get_scratch(sizeof(double) * 16 + sizeof(unsigned) * (hist_words + state_words), &ws);
+    int rc = get_scratch(sizeof(double) * 16 + sizeof(unsigned) * (hist_words + state_words), &ws, (hipStream_t)stream);
     if (rc) return rc;
     B4D_HIP(hipMemcpyAsync(ws, q_host, sizeof(double) * nq, hipMemcpyHostToDevice, st));
     B4D_HIP(hipStreamSynchronize(st));
@@ -929,7 +936,7 @@ int b4d_psd_stats(const float* psd, int batch, int ny, int nx, double* out, void
     a.nfine = square ? 2 * (nx / 2 + 2) + 1 : 0;
     const size_t nd = (size_t)batch * (8 * a.nblk + a.ncoarse + a.nfine + 2) + 64;
     void* ws = nullptr;
-    int rc = get_scratch(sizeof(double) * nd + sizeof(int) * batch, &ws);
+    int rc = get_scratch(sizeof(double) * nd + sizeof(int) * batch, &ws, (hipStream_t)stream);
     if (rc) return rc;
     double* base = static_cast<double*>(ws);
     a.part = base;

@@ -1362,7 +1362,7 @@ int b4d_richardson_lucy(const float* frames, int batch, int h, int w, const floa
     const int py = ky / 2, px = kx / 2, H = h + 2 * py, W = w + 2 * px;
     const size_t n = (size_t)H * W, fp = (size_t)h * w;
     void* ws = nullptr;
-    int rc = get_scratch(sizeof(float) * (3 * n + 256 + (size_t)ky * kx) + 1024, &ws);
+    int rc = get_scratch(sizeof(float) * (3 * n + 256 + (size_t)ky * kx) + 1024, &ws, (hipStream_t)stream);
     if (rc) return rc;
     float* work = static_cast<float*>(ws);
     float* est = work + n;

@@ -86,10 +86,12 @@ _wiener_plans: dict = {}
 
 
 def _wiener_plan(h, w, psf, balance) -> _WienerPlan:
-    """Plans (DFT matrices, transposed filter, work buffers) are cached per (shape, PSF, balance, device)."""
+    """Plans (twiddles, transposed filter, work buffers) are cached per (shape, PSF, balance, device, stream): the work
+    buffers belong to the calls queued on ONE stream."""
     import torch
 
-    key = (int(h), int(w), psf.shape, psf.tobytes(), float(balance), torch.cuda.current_device())
+    key = (int(h), int(w), psf.shape, psf.tobytes(), float(balance), torch.cuda.current_device(),
+           int(torch.cuda.current_stream().cuda_stream))
     pl = _wiener_plans.get(key)
     if pl is None:
         if len(_wiener_plans) >= 4:

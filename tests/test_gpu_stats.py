@@ -145,3 +145,25 @@ def test_temporal_stats_packed_allreduce_and_row_block_overlap():
             dist.destroy_process_group()
     for a, b, c in zip(plain, one, blocks):
         assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_reduction_entry_points_on_two_streams(K):
+    """The second-stage reduction scratch is per stream (csrc/b4d_stats.hip: get_scratch): calls queued on two torch
+    streams, interleaved without any host synchronisation in between, must give the serial results."""
+    import torch
+
+    a = torch.from_numpy(synth.speckle_stack(6, 256, seed0=11)).cuda()
+    b = torch.from_numpy(synth.speckle_stack(6, 256, seed0=29)[:, ::-1].copy()).cuda()
+    want_a, want_b = K.moments_batch(a).cpu().numpy(), K.moments_batch(b).cpu().numpy()
+    want_sa, want_sb = K.sobel_laplace_batch(a).cpu().numpy(), K.sobel_laplace_batch(b).cpu().numpy()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            ga, gsa = K.moments_batch(a), K.sobel_laplace_batch(a)
+        with torch.cuda.stream(s2):
+            gb, gsb = K.moments_batch(b), K.sobel_laplace_batch(b)
+        s1.synchronize()
+        s2.synchronize()
+        assert np.array_equal(ga.cpu().numpy(), want_a) and np.array_equal(gb.cpu().numpy(), want_b)
+        assert np.array_equal(gsa.cpu().numpy(), want_sa) and np.array_equal(gsb.cpu().numpy(), want_sb)
