@@ -191,10 +191,10 @@ def secondary_cfg5(torch, cpu: bool):
 
 
 def secondary_cfg4(torch, dist, stack, world: int, rank: int, cpu: bool):
-    """BASELINE configs[3]: per-pixel temporal mean / variance / contrast.  Every rank streams ITS frames (the cfg2 stack,
-    256 frames of 2048^2 per GPU) into float64 sums, then ONE all-reduce of [count, sum_x, sum_xx] (64 MiB) crosses xGMI
-    (RCCL) and the maps are finalised from the reduced sums.  Reported: whole-job frames/s, the collective's own time,
-    and equality of the N-rank result with a single-rank run on a small stack."""
+    """BASELINE configs[3]: per-pixel temporal mean / variance / contrast of 8192 x 2048 x 2048 frames sharded over 8 GPUs =
+    1024 frames (16 GiB) per GPU.  Every rank streams ITS 1024 frames into float64 sums, then ONE all-reduce of
+    [count, sum_x, sum_xx] (64 MiB) crosses xGMI (RCCL) and the maps are finalised from the reduced sums.  Reported:
+    whole-job frames/s, the collective's own time, and equality of the N-rank result with a single-rank run on a small stack."""
     from barc4dip_amd.metrics.temporal import shard_bounds, temporal_stats
 
     T, H, W = (int(v) for v in stack.shape)
@@ -333,6 +333,13 @@ def main():
         cpu = not args.no_cpu
         secondary = {"note": "measured after the timed region of the headline; never part of `value`; HBM roof 8 TB/s; "
                              "byte models: SURVEY.md §8(d)"}
+        # cfg4's per-GPU shard is 1024 frames: extend the 256-frame cfg2 stack (the generator is deterministic per seed)
+        from barc4dip_amd import synth as _synth
+
+        try:
+            stack = torch.cat([stack, _synth.speckle_stack_device(1024 - T, N, seed0=777 + 100000 * rank)]) if T < 1024 else stack
+        except Exception:      # not enough free HBM for 16 GiB: keep the 256-frame shard
+            pass
         c4 = secondary_cfg4(torch, dist, stack, world, rank, cpu)
         if rank == 0:
             secondary["cfg4"] = c4
