@@ -39,6 +39,7 @@ _vp, _i, _u, _f, _d, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_double,
 SIGNATURES = {
     "b4d_version": (C.c_char_p, []),
     "b4d_last_error": (C.c_char_p, []),
+    "b4d_set_option": (_i, [C.c_char_p, _i]),
     "b4d_size_supported": (_i, [_i, _i]),
     "b4d_plan_create_general": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "b4d_fft2d_c2c": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

@@ -494,9 +494,14 @@ struct RowOutArgs {
     unsigned flags;
     float* part_val;     // C2R_MAG: per-workgroup arg-max partials (batch, gridDim.x)
     int* part_idx;
-    unsigned* hist;      // C2R_MAG, optional: (batch, 2048) counts of the magnitudes' top 11 key bits (first pass of the
-                         // exact median's radix select, b4d_select.hpp), accumulated with one global atomic per non-empty
-                         // bin and workgroup; zeroed by the caller
+    // C2R_MAG, optional (selw != null): the exact median's first select step, fused into the pass that produces the map.
+    // pred_bin = top-11-bit key bin the median is EXPECTED in; per frame, at selw + frame * sel_stride: word 1 += elements
+    // below that bin, word 2 += elements in it, word 3 = append cursor of compact + frame * ny * nx, which receives the bin's
+    // elements (all zeroed by the caller).  b4d_track.hip checks the expectation and finishes on the gathered ~10 %.
+    unsigned* selw;
+    int sel_stride;
+    unsigned pred_bin;
+    float* compact;
     int half;            // C2R_OUT: the map is even (R[-y,-x] = R[y,x], autocorrelation): transform rows 0..ny/2 only
                          // and write every row together with its point mirror
 };
@@ -617,33 +622,58 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
         p.part_val[frame * gridDim.x + blockIdx.x] = bv;
         p.part_idx[frame * gridDim.x + blockIdx.x] = bi;
     }
-    if (p.hist) {
-        // First pass of the median's radix select, fused into the pass that produces the map: one 2048-bin histogram per
-        // wave in the (now free) exchange buffer -- magnitudes crowd ~10 bins, so a wave's atomics conflict with each other
-        // but never with another wave's --, folded and pushed with one global atomic per non-empty bin.
+    if (p.selw && p.pred_bin) {
+        // counts of the magnitudes below / inside the expected median bin and the bin's elements themselves: lane counts,
+        // a workgroup scan, THREE global atomics per workgroup (no per-element atomics, no second read of the map)
         constexpr int NW = (T * SEQ + 63) / 64;
-        constexpr int HIST_WORDS = 2048 * NW;
-        static_assert(sizeof(lds_all) >= sizeof(unsigned) * (64 + HIST_WORDS) || NW == 0, "exchange buffer too small for the histograms");
-        unsigned* hl = reinterpret_cast<unsigned*>(lds_all) + 64;   // words 0..63: the arg-max partials above
-        __syncthreads();
-        for (int i = threadIdx.x; i < HIST_WORDS; i += T * SEQ) hl[i] = 0;
-        __syncthreads();
+        const unsigned pb = p.pred_bin;
+        unsigned cnt = 0, low = 0;
         if (live) {
-            unsigned* mine = hl + 2048 * w;
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 const float m0 = fabsf(v[j].y * p.scale), m1 = fabsf(v[j].x * p.scale);
-                if (m0 == m0) atomicAdd(&mine[(__float_as_uint(m0) | 0x80000000u) >> 21], 1u);   // f2key of a value >= 0
-                if (m1 == m1) atomicAdd(&mine[(__float_as_uint(m1) | 0x80000000u) >> 21], 1u);
+                const unsigned b0 = (__float_as_uint(m0) | 0x80000000u) >> 21, b1 = (__float_as_uint(m1) | 0x80000000u) >> 21;   // f2key(x >= 0) >> 21
+                cnt += (m0 == m0 && b0 == pb) ? 1u : 0u;
+                cnt += (m1 == m1 && b1 == pb) ? 1u : 0u;
+                low += (m0 == m0 && b0 < pb) ? 1u : 0u;
+                low += (m1 == m1 && b1 < pb) ? 1u : 0u;
             }
         }
-        __syncthreads();
-        unsigned* gh = p.hist + frame * 2048;
-        for (int i = threadIdx.x; i < 2048; i += T * SEQ) {
-            unsigned t = hl[i];
+        unsigned incl = cnt;
 #pragma unroll
-            for (int r = 1; r < NW; ++r) t += hl[2048 * r + i];
-            if (t) atomicAdd(&gh[i], t);
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) low += __shfl_down(low, o, 64);
+        unsigned* hl = reinterpret_cast<unsigned*>(lds_all) + 64;   // words 0..63: the arg-max partials above
+        __syncthreads();
+        if (lane == 63) hl[w] = incl;          // wave totals of the bin
+        if (lane == 0) hl[NW + 1 + w] = low;   // wave totals below the bin
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned run = 0, lo = 0;
+            for (int i = 0; i < NW; ++i) {
+                const unsigned t = hl[i];
+                hl[i] = run;
+                run += t;
+                lo += hl[NW + 1 + i];
+            }
+            unsigned* sw = p.selw + frame * p.sel_stride;
+            if (lo) atomicAdd(&sw[1], lo);
+            if (run) atomicAdd(&sw[2], run);
+            hl[NW] = run ? atomicAdd(&sw[3], run) : 0u;
+        }
+        __syncthreads();
+        if (cnt) {
+            float* dst = p.compact + frame * (size_t)ny * NX + hl[NW] + hl[w] + (incl - cnt);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const float m0 = fabsf(v[j].y * p.scale), m1 = fabsf(v[j].x * p.scale);
+                if (m0 == m0 && ((__float_as_uint(m0) | 0x80000000u) >> 21) == pb) *dst++ = m0;
+                if (m1 == m1 && ((__float_as_uint(m1) | 0x80000000u) >> 21) == pb) *dst++ = m1;
+            }
         }
     }
 }

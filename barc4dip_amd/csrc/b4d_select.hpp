@@ -22,7 +22,7 @@ __device__ __forceinline__ float key2f(unsigned k) {
 // compact (optional, >= n floats of global scratch owned by this workgroup): after the first pass the elements of the
 // selected 11-bit bin are gathered there and the two remaining passes (and the caller's next_larger_key) stream that
 // short array instead of the whole map; *cx / *cn return the array / length to continue on.
-// pass_begin = 1 resumes after a first pass done elsewhere (k_row_c2r's fused histogram + k_track_gather): x then
+// pass_begin = 1 resumes after a first pass done elsewhere (k_row_c2r counts and gathers the expected median bin): x then
 // holds only the elements of the selected top-11-bit bin `prefix0 >> 21`, below0 = number of elements under that bin.
 template <int REP = 1>
 __device__ inline unsigned radix_select(const float* __restrict__ x, unsigned n, unsigned k, unsigned* hist,

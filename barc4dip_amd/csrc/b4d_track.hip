@@ -8,6 +8,8 @@
 //   k_track_fin  first-occurrence arg-max, exact median by 3-pass radix select, 3x3 Taylor step
 // Image spectra are computed once and reused by every template (the reference re-transforms
 // the same frame 18 times per time step, metrics/speckles.py:347-415).
+#include <cstring>
+
 #include "b4d_fft2d.hpp"
 #include "b4d_select.hpp"
 
@@ -146,6 +148,8 @@ struct FinArgs {
     const float* med_src;
     size_t stride;
     float* compact;         // optional (pairs, stride) scratch for the median's gathered bin (b4d_select.hpp)
+    const unsigned* skip;   // optional: pair i is left alone when skip[i * skip_stride] != 0 (finished by k_track_fin2)
+    int skip_stride;
 };
 
 // peak quality + Taylor step of one pair (one lane), op for op like tracking.py:314-375 (float32 scalars, no contraction)
@@ -194,6 +198,7 @@ __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
     __shared__ float sv[16];
     __shared__ int si[16];
     const size_t pair = blockIdx.x;
+    if (p.skip && p.skip[pair * p.skip_stride]) return;
     int mny = p.ny, mnx = p.nx, oy = p.ny / 2, ox = p.nx / 2;
     if (p.geom) {
         mny = p.geom[4 * pair];
@@ -264,103 +269,34 @@ static int launch_track_fin(const FinArgs& fa, int pairs, hipStream_t st) {
 // workgroup per pair finishes on the gathered ~10 % of the map: passes 2-3 of the select, arg-max partials, Taylor step.
 struct SelState {
     unsigned bin, below, count, fill;   // selected top-11-bit bin, elements under it, elements in it, gather cursor
+    unsigned ok, pad[3];                // the median is in the expected bin: k_row_c2r has already counted and gathered it
 };
-constexpr int GATHER_SPLIT = 8;
-constexpr int GATHER_STAGE = 8192;   // floats staged in LDS between two flushes (a power-of-two multiple of 1024)
+constexpr int SEL_WORDS = sizeof(SelState) / sizeof(unsigned);
 
-// grid (GATHER_SPLIT, pairs), block 256
-__global__ void __launch_bounds__(256) k_track_gather(const float* __restrict__ mag, size_t n, const unsigned* __restrict__ hist,
-                                                      SelState* __restrict__ sel, float* __restrict__ compact) {
-    __shared__ unsigned sh[3];
-    const size_t pair = blockIdx.y;
-    const unsigned* h = hist + pair * 2048;
-    const unsigned k = (unsigned)((n & 1u) ? n / 2 : n / 2 - 1);   // rank of the (lower) middle element
-    if (threadIdx.x < 64) {   // one wave: 32 bins per lane, wave scan (as in radix_select)
-        constexpr int per = 2048 / 64;
-        unsigned s = 0;
-        for (int i = 0; i < per; ++i) s += h[threadIdx.x * per + i];
-        unsigned incl = s;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned t = __shfl_up(incl, o, 64);
-            if ((int)threadIdx.x >= o) incl += t;
-        }
-        const unsigned excl = incl - s;
-        if (k >= excl && k < incl) {
-            unsigned run = excl;
-            for (int i = 0; i < per; ++i) {
-                const unsigned c = h[threadIdx.x * per + i];
-                if (k < run + c) {
-                    sh[0] = threadIdx.x * per + i;
-                    sh[1] = run;
-                    sh[2] = c;
-                    break;
-                }
-                run += c;
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned bin = sh[0];
+// Whitened correlation maps (signal/tracking.py:280-285) have sum corr^2 = 1 and corr is REAL (a Hermitian spectrum), so
+// away from the peak it is Gaussian with variance 1 / N and |corr| half-normal: median 0.6745 / sqrt(N) (x sqrt(1 - peak^2),
+// a per cent or so; observed on the cfg3 protocol: 6.55e-4 ... 6.58e-4 against 6.587e-4).  The top-11-bit bin of that value
+// is where the median of nearly every pair falls.  k_row_c2r counts the elements below / inside that bin and gathers the
+// bin while it writes the map; pairs whose counts put the median elsewhere take the full three-pass select on the map
+// (k_track_fin).  Exactness never depends on the guess.
+static bool g_track_predict = true;     // b4d_set_option("track_predict_bin", 0 / 1): tests run both ways
+static unsigned predicted_median_bin(size_t n) {
+    if (!g_track_predict) return 0u;
+    const float med = (float)(0.6744897501960817 / std::sqrt((double)n));
+    unsigned bits;
+    memcpy(&bits, &med, sizeof(bits));
+    return 1024u + (bits >> 21);
+}
+
+// grid (ceil(pairs / 64)), block 64: the expectation holds for pair i when the median's rank falls inside the expected bin
+// (and the gathered count agrees with the counted one)
+__global__ void __launch_bounds__(64) k_track_select(size_t n, SelState* __restrict__ sel, unsigned pred, int pairs) {
+    const int pair = blockIdx.x * 64 + threadIdx.x;
+    if (pair >= pairs) return;
     SelState* st = sel + pair;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->bin = bin;
-        st->below = sh[1];
-        st->count = sh[2];
-    }
-    const float* x = mag + pair * n;
-    float* out = compact + pair * n;
-    // This workgroup's slice, in whole float4s.  Matches are staged in LDS (wave-aggregated append: one LDS atomic per
-    // wave and ballot) and flushed in blocks with ONE global atomic each -- a cursor bumped per wave would put tens of
-    // thousands of same-address atomics on every pair.
-    __shared__ float stage[GATHER_STAGE];
-    __shared__ unsigned cnt, gbase;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    const size_t n4 = n / 4, per4 = (n4 + gridDim.x - 1) / gridDim.x, a4 = blockIdx.x * per4, b4 = min(n4, a4 + per4);
-    auto put = [&](float f) {
-        const bool m = (f == f) && ((__float_as_uint(f) >> 21) == (bin & 1023u)) && (bin >= 1024u) && !(__float_as_uint(f) & 0x80000000u);
-        const unsigned long long bal = __ballot(m);
-        if (bal == 0) return;
-        const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(&cnt, (unsigned)__popcll(bal));
-        base = __shfl(base, leader, 64);
-        if (m) stage[base + __popcll(bal & ((1ull << lane) - 1ull))] = f;
-    };
-    auto flush = [&]() {   // whole workgroup
-        __syncthreads();
-        const unsigned c = cnt;
-        if (threadIdx.x == 0) gbase = c ? atomicAdd(&st->fill, c) : 0u;
-        __syncthreads();
-        for (unsigned i = threadIdx.x; i < c; i += blockDim.x) out[gbase + i] = stage[i];
-        __syncthreads();
-        if (threadIdx.x == 0) cnt = 0;
-        __syncthreads();
-    };
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    // four 16-byte loads per lane in flight (the pass is a pure stream: with one load per lane it is latency-bound at
-    // ~3.8 TB/s); whole waves take part in every ballot; a round appends at most 4096 values, two rounds fill the stage
-    const float4 nan4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-    const size_t span = b4 > a4 ? b4 - a4 : 0, rounds = (span + 1023) / 1024;
-    for (size_t r = 0; r < rounds; ++r) {
-        if ((r & (GATHER_STAGE / 4096 - 1)) == 0 && r) flush();
-        const size_t i = a4 + r * 1024 + threadIdx.x;
-        float4 a[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = i + 256 * k < b4 ? x4[i + 256 * k] : nan4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            put(a[k].x); put(a[k].y); put(a[k].z); put(a[k].w);
-        }
-    }
-    if (blockIdx.x == gridDim.x - 1) {   // ragged tail of the map (n % 4 elements); the stage has room: see the flush rule
-        flush();
-        const size_t t0 = 4 * n4;
-        const float f = (t0 + threadIdx.x < n) ? x[t0 + threadIdx.x] : __builtin_nanf("");
-        if (threadIdx.x < 64) put(f);
-    }
-    flush();
+    const unsigned k = (unsigned)((n & 1u) ? n / 2 : n / 2 - 1);   // rank of the (lower) middle element
+    st->bin = pred;
+    st->ok = (pred != 0u && k >= st->below && k < st->below + st->count && st->fill == st->count) ? 1u : 0u;
 }
 
 // grid (pairs), block 1024, dynamic LDS FIN_LDS bytes
@@ -371,6 +307,7 @@ __global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, const SelState* 
     __shared__ float sv[16];
     __shared__ int si[16];
     const size_t pair = blockIdx.x;
+    if (!sel[pair].ok) return;    // the expectation failed: k_track_fin does the whole selection on the map
     const int mny = p.ny, mnx = p.nx, oy = p.ny / 2, ox = p.nx / 2;
     const unsigned n = (unsigned)mny * mnx;
     const float* mag = p.mag + pair * (size_t)n;
@@ -415,7 +352,7 @@ __global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, const SelState* 
     track_finish(p, pair, mag, mny, mnx, oy, ox, bv, bi, med);
 }
 
-static int launch_track_fin2(const FinArgs& fa, const unsigned* hist, SelState* sel, int pairs, hipStream_t st) {
+static int launch_track_fin2(const FinArgs& fa, SelState* sel, unsigned pred, int pairs, hipStream_t st) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
@@ -423,10 +360,13 @@ static int launch_track_fin2(const FinArgs& fa, const unsigned* hist, SelState* 
     });
     B4D_HIP(attr_err);
     const size_t n = (size_t)fa.ny * fa.nx;
-    hipLaunchKernelGGL(k_track_gather, dim3(GATHER_SPLIT, pairs), dim3(256), 0, st, fa.mag, n, hist, sel, fa.compact);
+    hipLaunchKernelGGL(k_track_select, dim3((pairs + 63) / 64), dim3(64), 0, st, n, sel, pred, pairs);
     hipLaunchKernelGGL(k_track_fin2, dim3(pairs), dim3(1024), FIN_LDS, st, fa, (const SelState*)sel);
     B4D_HIP(hipGetLastError());
-    return B4D_OK;
+    FinArgs fb = fa;            // the pairs whose expectation failed (all of them when it is switched off)
+    fb.skip = &sel[0].ok;
+    fb.skip_stride = SEL_WORDS;
+    return launch_track_fin(fb, pairs, st);
 }
 
 // ------------------------------------------------------------------------------------ NCC template matching
@@ -953,6 +893,15 @@ int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* 
     return B4D_OK;
 }
 
+int b4d_set_option(const char* name, int value) {
+    if (!name) return fail(B4D_EINVAL, "null option name");
+    if (!strcmp(name, "track_predict_bin")) {
+        g_track_predict = value != 0;
+        return B4D_OK;
+    }
+    return fail(B4D_EINVAL, std::string("unknown option: ") + name);
+}
+
 int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const float* tpl_src, int ntplsrc,
                           const int32_t* tpl_frame, const int32_t* tpl_roi, int ntpl, const int32_t* pair_img,
                           const int32_t* pair_tpl, int npairs, int subpixel, double eps, double* out, int32_t* peak_ij,
@@ -992,7 +941,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     add(sizeof(float) * fpix * pc);           // median scratch (gathered bin)
     add(sizeof(float) * 2048 * (size_t)pc);
     add(sizeof(int) * 2048 * (size_t)pc);
-    add(sizeof(unsigned) * (2048 + 4) * (size_t)pc);   // first-pass histograms + select state of the median
+    add(sizeof(unsigned) * SEL_WORDS * (size_t)pc);   // select state of the median
     Arena ar;
     int rc = track_arena(pl, need, &ar);
     if (rc) return rc;
@@ -1008,8 +957,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     float* medws = ar.take<float>(fpix * pc);
     float* pval = ar.take<float>((size_t)2048 * pc);
     int* pind = ar.take<int>((size_t)2048 * pc);
-    unsigned* mhist = ar.take<unsigned>((size_t)(2048 + 4) * pc);
-    SelState* msel = reinterpret_cast<SelState*>(mhist + (size_t)2048 * pc);
+    SelState* msel = reinterpret_cast<SelState*>(ar.take<unsigned>((size_t)SEL_WORDS * pc));
 
     // ---- source descriptors: images (full frame, z-scored), then templates (ROI, z-scored, zero elsewhere)
     std::vector<RowSrc> h(nsrc);
@@ -1056,8 +1004,12 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         ra.ct_w = pl->ct_w;
         ra.part_val = pval;
         ra.part_idx = pind;
-        ra.hist = mhist;
-        B4D_HIP(hipMemsetAsync(mhist, 0, sizeof(unsigned) * (2048 + 4) * (size_t)pc, st));   // histograms and gather cursors
+        const unsigned pred = predicted_median_bin(fpix);
+        ra.selw = reinterpret_cast<unsigned*>(msel);
+        ra.sel_stride = SEL_WORDS;
+        ra.pred_bin = pred;
+        ra.compact = medws;
+        B4D_HIP(hipMemsetAsync(msel, 0, sizeof(SelState) * (size_t)pc, st));   // counts, cursors, verdicts
         int nblk = 0;
         if ((rc = dispatch_c2r(pl, ra, np, st, C2R_MAG, nullptr, &nblk))) return rc;
         FinArgs fa{};
@@ -1072,7 +1024,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         fa.nblk = nblk;
         fa.subpixel = subpixel;
         fa.eps = eps;
-        if ((rc = launch_track_fin2(fa, mhist, msel, np, st))) return rc;
+        if ((rc = launch_track_fin2(fa, msel, pred, np, st))) return rc;
         B4D_HIP(hipGetLastError());
     }
     return B4D_OK;

@@ -341,3 +341,33 @@ def test_cfg3_size(gs):
     assert worst["sub32"] <= 1e-5 and worst["peak32"] <= 2.5e-4 and worst["snr32"] <= 5e-4
     # ground truth of the protocol: abs shifts = the imposed spiral on every ROI
     assert np.all(np.rint(res[:9 * T, 0]).reshape(T, 9) == sh[:, 0:1]) and np.all(np.rint(res[:9 * T, 1]).reshape(T, 9) == sh[:, 1:2])
+
+
+def test_median_bin_prediction_is_only_a_route(gs):
+    """b4d_phase_correlation gathers the EXPECTED median bin of every |corr| map while it writes the map (whitened maps:
+    median ~ 0.6745 / sqrt(N)) and falls back to a second read of the map per pair when the histogram disagrees.  Both
+    routes must give bit-identical rows -- with the expectation switched off every pair takes the fallback -- and an
+    un-whitened-looking input (a constant template region: degenerate map) must survive a wrong expectation."""
+    from barc4dip_amd import _ffi
+
+    stack, sh = synth.shifted_stack(4, 512, seed=77, max_shift=12)
+    rois = [(100, 221, 90, 211), (300, 421, 280, 401)]
+    tpl_frame = [0, 0] + [max(t - 1, 0) for t in range(4) for _ in range(2)]
+    tpl_roi = rois + rois * 4
+    pair_img = [t for t in range(4) for _ in range(2)] * 2
+    pair_tpl = [k for _ in range(4) for k in range(2)] + [2 + 2 * t + k for t in range(4) for k in range(2)]
+    flat = stack.copy()
+    flat[1, 100:221, 90:211] = 7.0            # a constant ROI: z-score 0 -> all-zero cross spectrum -> the map is not Rayleigh
+    lib = _ffi.lib()
+    out = {}
+    try:
+        for mode in (1, 0):
+            assert lib.b4d_set_option(b"track_predict_bin", mode) == 0
+            out[mode] = (gs.phase_correlation_batch(stack, stack, tpl_frame, tpl_roi, pair_img, pair_tpl, return_peak_ij=True),
+                         gs.phase_correlation_batch(flat, flat, tpl_frame, tpl_roi, pair_img, pair_tpl, return_peak_ij=True))
+    finally:
+        lib.b4d_set_option(b"track_predict_bin", 1)
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
+    assert lib.b4d_set_option(b"no_such_option", 1) != 0
+    assert np.all(np.rint(out[1][0][0][:8, 0]).reshape(4, 2) == sh[:, 0:1])

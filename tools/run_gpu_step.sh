@@ -1,8 +1,4 @@
-mkdir -p gpurun_out/r2s
-timeout -k 10 600 python bench.py --no-cpu > gpurun_out/r2s/bench.json 2> gpurun_out/r2s/bench.err; echo "bench rc $?"
-python - <<'PY'
-import json
-l=json.load(open("gpurun_out/r2s/bench.json"))
-print(l["value"]); print(json.dumps(l["secondary"]["cfg4"]))
-PY
-timeout -k 10 300 python tools/dev_general_track.py 2>&1 | tail -3
+mkdir -p gpurun_out/r2t
+timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py tests/test_gpu_metrics.py -x -q -m gpu > gpurun_out/r2t/pytest.log 2>&1; tail -5 gpurun_out/r2t/pytest.log
+timeout -k 10 300 python tools/bench_configs.py 3 2>&1 | tail -1
+bash tools/prof_stats.sh r2t/cfg3 tools/bench_configs.py 3 > /dev/null; python3 tools/prof_summary.py gpurun_out/r2t/cfg3 > gpurun_out/r2t/s.txt; head -9 gpurun_out/r2t/s.txt
