@@ -419,6 +419,26 @@ int general_fft2d_c2c(b4d_plan* pl, const float2* in, int batch, int inverse, fl
 
 int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
+    if (pl->large && wmr_supported(nx) && wmr_supported(ny)) {
+        // mixed-radix kernels on both sides: two forward half-spectrum passes per operand, product + inverse columns, inverse
+        // row pairs (b4d_wiener_mr.hip); the chunk buffers hold complex (chunk, ny, nx), twice a half spectrum
+        const size_t selems = wmr_spectrum_elems(ny, nx);
+        for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
+            const int nb = std::min(pl->chunk, batch - b0);
+            const size_t off = (size_t)b0 * npix;
+            float* scratch = reinterpret_cast<float*>(pl->gbuf3 + selems * nb);
+            int rc = wmr_forward_spectra(a + off, nb, ny, nx, pl->tw_x, pl->tw_y, pl->gbuf1, scratch, st);
+            if (rc == B4D_OK) rc = wmr_forward_spectra(b + off, nb, ny, nx, pl->tw_x, pl->tw_y, pl->gbuf2, scratch, st);
+            if (rc == B4D_OK)
+                rc = wmr_product_inverse(pl->gbuf1, pl->gbuf2, nullptr, nullptr, nb, ny, nx, pl->tw_y, pl->gbuf3, 0, 0.f,
+                                         flags & B4D_REMOVE_MEAN, st);
+            if (rc == B4D_OK) rc = wmr_rows_real_out(pl->gbuf3, nb, ny, nx, pl->tw_x, corr + off, st);
+            if (rc == B4D_OK && (flags & B4D_NORM_PEAK))
+                rc = normalise_by_absmax(corr + off, (size_t)npix, nb, reinterpret_cast<float*>(pl->gbuf1), st);
+            if (rc) return rc;
+        }
+        return B4D_OK;
+    }
     for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
         const int nb = std::min(pl->chunk, batch - b0);
         const size_t off = (size_t)b0 * npix;

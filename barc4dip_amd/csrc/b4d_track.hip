@@ -12,6 +12,7 @@
 
 #include "b4d_fft2d.hpp"
 #include "b4d_select.hpp"
+#include "b4d_wiener_mr.hpp"
 
 namespace b4d {
 
@@ -773,9 +774,96 @@ int normalise_by_absmax(float* x, size_t n, int batch, float* scratch, hipStream
 
 // phase correlation on a general-length plan (DFT-matrix or fused mixed-radix transforms): same steps as the
 // power-of-two path with full complex spectra
+// General sizes whose two sides have mixed-radix kernels (b4d_wiener_mr.hip; 2560 x 2160 detector frames ...): half spectra in
+// the transposed [k][ky] layout, three passes per pair (product + inverse columns, inverse row pairs -> |corr| map + arg-max
+// partials, selection) instead of full-complex DFT-matrix / fused transforms with transposes in between.
+static int wmr_phase_correlation(b4d_plan* pl, const float* images, int nimg, const float* tpl_src, const int32_t* tpl_frame,
+                                 const int32_t* tpl_roi, int ntpl, const int32_t* pair_img, const int32_t* pair_tpl, int npairs,
+                                 int subpixel, double eps, double* out, int32_t* peak_ij, hipStream_t st) {
+    const int ny = pl->ny, nx = pl->nx, nsrc = nimg + ntpl, hp = (ny + 1) / 2, qpf = wmr_quads_per_frame(ny);
+    const size_t npix = (size_t)ny * nx, selems = wmr_spectrum_elems(ny, nx);
+    const int sc = std::max(1, pl->chunk), pc = std::max(1, std::min(npairs, pl->chunk));
+    size_t need = 0;
+    auto add = [&](size_t b) { need += ((b + 255) & ~(size_t)255) + 256; };
+    add(sizeof(float2) * selems * nsrc);
+    add(sizeof(float) * npix * sc);
+    add(sizeof(float) * (size_t)hp * sc);
+    add(sizeof(RowSrc) * nsrc);
+    add(sizeof(double) * 2 * ROI_SPLIT * nsrc);
+    add(sizeof(int) * 2 * (size_t)npairs);
+    add(sizeof(float2) * selems * pc);
+    add(sizeof(float) * npix * pc);
+    add(sizeof(float) * npix * pc);
+    add(sizeof(float) * (size_t)qpf * pc);
+    add(sizeof(int) * (size_t)qpf * pc);
+    add(sizeof(unsigned) * SEL_WORDS * (size_t)pc);
+    Arena ar;
+    int rc = track_arena(pl, need, &ar);
+    if (rc) return rc;
+    float2* spec = ar.take<float2>(selems * nsrc);
+    float* canvas = ar.take<float>(npix * sc);
+    float* scratch = ar.take<float>((size_t)hp * sc);
+    RowSrc* srcs = ar.take<RowSrc>(nsrc);
+    double* roi_part = ar.take<double>((size_t)2 * ROI_SPLIT * nsrc);
+    int* pidx = ar.take<int>(2 * (size_t)npairs);
+    float2* G = ar.take<float2>(selems * pc);
+    float* mag = ar.take<float>(npix * pc);
+    float* medws = ar.take<float>(npix * pc);
+    float* pval = ar.take<float>((size_t)qpf * pc);
+    int* pind = ar.take<int>((size_t)qpf * pc);
+    SelState* msel = reinterpret_cast<SelState*>(ar.take<unsigned>((size_t)SEL_WORDS * pc));
+    std::vector<RowSrc> h(nsrc);
+    for (int i = 0; i < nimg; ++i) h[i] = RowSrc{i, 0, ny, 0, nx, 0.f, 1.f, 0};
+    for (int k = 0; k < ntpl; ++k)
+        h[nimg + k] = RowSrc{tpl_frame[k], tpl_roi[4 * k], tpl_roi[4 * k + 1], tpl_roi[4 * k + 2], tpl_roi[4 * k + 3], 0.f, 1.f, 0};
+    std::vector<int> hpi(2 * (size_t)npairs);
+    for (int i = 0; i < npairs; ++i) {
+        hpi[i] = pair_img[i];
+        hpi[npairs + i] = nimg + pair_tpl[i];
+    }
+    B4D_HIP(hipMemcpyAsync(srcs, h.data(), sizeof(RowSrc) * nsrc, hipMemcpyHostToDevice, st));
+    B4D_HIP(hipMemcpyAsync(pidx, hpi.data(), sizeof(int) * hpi.size(), hipMemcpyHostToDevice, st));
+    B4D_HIP(hipStreamSynchronize(st));
+    if ((rc = roi_stats(images, ny, nx, eps, srcs, nimg, roi_part, st))) return rc;
+    if ((rc = roi_stats(tpl_src, ny, nx, eps, srcs + nimg, ntpl, roi_part + (size_t)2 * ROI_SPLIT * nimg, st))) return rc;
+    const dim3 eg((unsigned)((npix + 255) / 256));
+    for (int s0 = 0; s0 < nsrc;) {   // spectra, once per distinct image / template; never straddle the two frame arrays
+        const int n = std::min(sc, (s0 < nimg ? nimg : nsrc) - s0);
+        hipLaunchKernelGGL(k_embed_roi, dim3(eg.x, n), dim3(256), 0, st, s0 < nimg ? images : tpl_src, ny, nx, srcs + s0, canvas);
+        B4D_HIP(hipGetLastError());
+        if ((rc = wmr_forward_spectra(canvas, n, ny, nx, pl->tw_x, pl->tw_y, spec + selems * s0, scratch, st))) return rc;
+        s0 += n;
+    }
+    for (int p0 = 0; p0 < npairs; p0 += pc) {
+        const int np = std::min(pc, npairs - p0);
+        if ((rc = wmr_product_inverse(spec, spec, pidx + p0, pidx + npairs + p0, np, ny, nx, pl->tw_y, G, 1, (float)eps, 0u, st))) return rc;
+        const unsigned pred = predicted_median_bin(npix);
+        B4D_HIP(hipMemsetAsync(msel, 0, sizeof(SelState) * (size_t)pc, st));
+        if ((rc = wmr_rows_magnitude(G, np, ny, nx, pl->tw_x, mag, pval, pind, reinterpret_cast<unsigned*>(msel), SEL_WORDS, pred, medws, st)))
+            return rc;
+        FinArgs fa{};
+        fa.mag = mag;
+        fa.compact = medws;
+        fa.part_val = pval;
+        fa.part_idx = pind;
+        fa.out = out + (size_t)p0 * 4;
+        fa.peak_ij = peak_ij ? peak_ij + (size_t)p0 * 2 : nullptr;
+        fa.ny = ny;
+        fa.nx = nx;
+        fa.nblk = qpf;
+        fa.subpixel = subpixel;
+        fa.eps = eps;
+        if ((rc = launch_track_fin2(fa, msel, pred, np, st))) return rc;
+    }
+    return B4D_OK;
+}
+
 static int general_phase_correlation(b4d_plan* pl, const float* images, int nimg, const float* tpl_src, const int32_t* tpl_frame,
                                      const int32_t* tpl_roi, int ntpl, const int32_t* pair_img, const int32_t* pair_tpl, int npairs,
                                      int subpixel, double eps, double* out, int32_t* peak_ij, hipStream_t st) {
+    if (pl->large && wmr_supported(pl->ny) && wmr_supported(pl->nx))
+        return wmr_phase_correlation(pl, images, nimg, tpl_src, tpl_frame, tpl_roi, ntpl, pair_img, pair_tpl, npairs, subpixel, eps, out,
+                                     peak_ij, st);
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx, nsrc = nimg + ntpl, nblk = 256;
     const int pc = std::max(1, std::min(npairs, pl->chunk));
     size_t need = 0;

@@ -25,7 +25,7 @@
 // float32 rounding of the scale (the maximum is only known after the first pass over the frame).
 // HBM/MALL traffic per frame at 4096^2, sigma 1.5: frame in 67 MB + spectrum out 67 + column in/out 135 + filter 67 +
 // spectrum in 67 + frame out 67 = 470 MB (the route it replaces moved 938 MB in 9 kernels).
-#include "b4d_common.hpp"
+#include "b4d_fft2d.hpp"   // cross_power, argmax_merge
 #include "b4d_mixed.hpp"
 #include "b4d_wiener_mr.hpp"
 
@@ -37,7 +37,7 @@ constexpr int WMR_Q = 4;   // row pairs per workgroup of the row kernels: 4 x 16
 
 template <class MX>
 __host__ __device__ constexpr size_t wmr_rows_lds() {
-    return sizeof(float2) * ((size_t)WMR_Q * MX::BUF + MX::M1) + sizeof(float) * (WMR_Q * MX::LANES / 64);
+    return sizeof(float2) * ((size_t)WMR_Q * MX::BUF + MX::M1) + sizeof(float) * (4 * (WMR_Q * MX::LANES / 64) + 8);
 }
 
 // Work index j -> quad.  Quads 2 m and 2 m + 1 of a frame share every 128-byte line of the transposed spectrum (their
@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
 // MODE 0: times the Wiener filter `filt` (deconvolve_psf).  MODE 1 (fft -> psd -> autocorr at general sizes,
 // signal/fft.py:261-309 + signal/corr.py:256-320): P = |F|^2 (DC zeroed when flags & B4D_REMOVE_MEAN) replaces the product,
 // is stored as a REAL column to Pt (same [k][ky] layout, pitch g.Hp floats) when Pt != null, and is what the inverse
-// transform runs on (skipped when `inverse` == 0: PSD only).
+// transform runs on (skipped when `inverse` == 0: PSD only).  MODE 2: forward transform only, F written back in natural
+// order (the 2-D half spectra of images / templates for tracking and xcorr2d).
 template <class MY, int MODE>
 __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ T, const float2* __restrict__ filt,
                                                             const float2* __restrict__ twN, const float* __restrict__ pmax,
@@ -222,6 +223,14 @@ __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ 
     __syncthreads();
     MY::stage3(buf, tid);
     __syncthreads();
+    if (MODE == 2) {
+        typename MY::template PosIter<LANES> pf(tid);
+        for (int n = tid; n < N; n += LANES) {
+            x[n] = buf[pf.pos()];
+            pf.up();
+        }
+        return;
+    }
     // inverse = conj(forward(conj(.))): inputs conj(X[n] W[n]) gathered from where the forward transform left X[n]
 #pragma unroll
     for (int r = 0; r < RD; ++r) {
@@ -361,6 +370,205 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_inv(const float2*
             if (wb) orow[g.w + x] = fok ? vb * fsc : 0.f;
         }
         __syncthreads();   // the row buffers are free for the next quad
+    }
+}
+
+// Cross spectrum + inverse column transform of one (image, template) pair and column k: c = A conj(B) [/ (|c| + eps),
+// signal/tracking.py:280-281], DC bin zeroed with B4D_REMOVE_MEAN (xcorr2d: both means removed), inverse along ky, G written
+// to the pair's transposed workspace.  A, B: 2-D half spectra from k_wmr_cols<., 2>, indexed through ia / ib (null: the pair).
+// grid (npairs * Wh), block LANES
+template <class MY, bool WHITEN>
+__global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols_prod(const float2* __restrict__ A, const float2* __restrict__ B,
+                                                                 const int* __restrict__ ia, const int* __restrict__ ib, float2* __restrict__ G,
+                                                                 const float2* __restrict__ twN, WmrGeom g, float eps, unsigned flags) {
+    __shared__ __attribute__((aligned(16))) float2 buf[MY::BUF];
+    __shared__ float2 tw2[MY::M1];
+    constexpr int R1 = MY::R1, M1 = MY::M1, LANES = MY::LANES, RD = MY::ROUNDS1, N = MY::N;
+    const int tid = threadIdx.x;
+    const int col = blockIdx.x, pair = col / g.Wh, k = col - pair * g.Wh;
+    const size_t sa = ia ? ia[pair] : pair, sb = ib ? ib[pair] : pair;
+    const float2* xa = A + (sa * g.Wh + k) * g.Hp;
+    const float2* xb = B + (sb * g.Wh + k) * g.Hp;
+    float2* xo = G + (size_t)col * g.Hp;
+    MY::build_tw2(tw2, twN, tid);
+    float2 v[RD][R1];
+#pragma unroll
+    for (int r = 0; r < RD; ++r) {
+        const int mc = min(tid + r * LANES, M1 - 1);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const int n = M1 * n1 + mc;
+            float2 c = cross_power<WHITEN>(xa[n], xb[n], eps);
+            if (n == 0 && k == 0 && (flags & B4D_REMOVE_MEAN)) c = make_float2(0.f, 0.f);
+            v[r][n1] = make_float2(c.x, -c.y);   // inverse = conj(forward(conj(.)))
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RD; ++r) {
+        const int m = tid + r * LANES;
+        if (m < M1) MY::stage1_item(v[r], m, buf, twN);
+    }
+    __syncthreads();
+    MY::stage2(buf, tw2, tid);
+    __syncthreads();
+    MY::stage3(buf, tid);
+    __syncthreads();
+    typename MY::template PosIter<LANES> pk(tid);
+    for (int n = tid; n < N; n += LANES) {
+        const float2 z = buf[pk.pos()];
+        xo[n] = make_float2(z.x, -z.y);
+        pk.up();
+    }
+}
+
+// Last pass of general-size tracking: inverse row-pair transforms of G as in k_wmr_rows_out, epilogue = |value| / (H W)
+// written fftshift-ed (signal/tracking.py:283-285) plus one arg-max partial per quad (first occurrence in row-major order).
+template <class MX>
+__global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_mag(const float2* __restrict__ T, float* __restrict__ mag,
+                                                                    float* __restrict__ part_val, int* __restrict__ part_idx,
+                                                                    const float2* __restrict__ twN, WmrGeom g, int nframes, int qpf,
+                                                                    unsigned* __restrict__ selw, int sel_stride, unsigned pred_bin,
+                                                                    float* __restrict__ compact) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr int R1 = MX::R1, M1 = MX::M1, L = MX::LANES, RD = MX::ROUNDS1, N = MX::N, WG = WMR_Q * L;
+    const int tid = threadIdx.x, lt = tid % L;
+    float2* tw2 = sm + (size_t)WMR_Q * MX::BUF;
+    float* sv = reinterpret_cast<float*>(tw2 + M1);   // WG / 64 wave partials: values, then indices
+    int* si = reinterpret_cast<int*>(sv + WG / 64);
+    unsigned* hl = reinterpret_cast<unsigned*>(si + WG / 64);   // 2 (WG / 64) + 1 words: the median's expected-bin bookkeeping
+    for (int t = tid; t < M1; t += WG) tw2[t] = twN[R1 * t];
+    const int qpf2 = (qpf + 1) & ~1, nitems = (nframes * qpf2 + 15) & ~15;
+    auto next_item = [&](int j) {
+        for (j += gridDim.x; j < nitems && !quad_of(j, qpf, qpf2, nframes).valid; j += gridDim.x) {}
+        return j;
+    };
+    const size_t fpix = (size_t)g.H * g.W;
+    for (int q = next_item((int)blockIdx.x - (int)gridDim.x); q < nitems; q = next_item(q)) {
+        int ltq = lt, tidq = tid;   // opaque per-iteration copies (see k_wmr_rows_fwd)
+        const float2* twq = twN;
+        asm volatile("" : "+v"(ltq), "+v"(tidq), "+s"(twq));
+        const int subq = tidq / L;
+        float2* bufq = sm + (size_t)subq * MX::BUF;
+        const float2* tw2q = sm + (size_t)WMR_Q * MX::BUF;
+        const QuadRef qr = quad_of(q, qpf, qpf2, nframes);
+        const int f = qr.f, qi = qr.qi, pr = WMR_Q * qi + subq;
+        const bool act = pr < g.hp;
+        const int r0 = 2 * pr;
+        const bool has_b = act && r0 + 1 < g.H;
+        {
+            const int j = tidq & (WMR_Q - 1), kk = tidq / WMR_Q, pj = WMR_Q * qi + j;
+            float2* bj = sm + (size_t)j * MX::BUF;
+            const bool hb = 2 * pj + 1 < g.H;
+            const float2* src = T + (size_t)f * g.Wh * g.Hp + 2 * min(pj, g.hp - 1);
+            for (int k = kk; k < g.Wh; k += L) {
+                const float4 p = *reinterpret_cast<const float4*>(src + (size_t)k * g.Hp);
+                const float bx = hb ? p.z : 0.f, by = hb ? p.w : 0.f;
+                bj[k] = make_float2(p.x - by, -(p.y + bx));
+                if (k != 0 && 2 * k != N) bj[N - k] = make_float2(p.x + by, p.y - bx);
+            }
+        }
+        __syncthreads();
+        const int ltr = (ltq + 64 * subq) % L;
+        float2 v[RD][R1];
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+            const int mc = min(ltr + r * L, M1 - 1);
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) v[r][n1] = bufq[M1 * n1 + mc];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+            const int m = ltr + r * L;
+            if (m < M1) MX::stage1_item(v[r], m, bufq, twq);
+        }
+        __syncthreads();
+        MX::stage2(bufq, tw2q, ltr);
+        __syncthreads();
+        MX::stage3(bufq, ltr);
+        __syncthreads();
+        const int ra = (r0 + g.H / 2) % g.H, rb = (r0 + 1 + g.H / 2) % g.H;
+        float* mf = mag + (size_t)f * fpix;
+        float bv = -1.0f;
+        int bi = 0x7fffffff;
+        unsigned cnt = 0, low = 0;   // elements of this lane inside / below the bin the median is expected in (b4d_track.hip)
+        auto kbin = [](float m) { return (__float_as_uint(m) | 0x80000000u) >> 21; };   // f2key(m >= 0) >> 21
+        typename MX::template PosIter<L> pk_it(ltq);
+        for (int x = ltq; x < g.W; x += L) {
+            const float2 z = bufq[pk_it.pos()];
+            pk_it.up();
+            const float ma = fabsf(z.x * g.inv), mb = fabsf(z.y * g.inv);   // conj(buf): real part row a, -imaginary part row b
+            const int c = (x + g.W / 2) % g.W;
+            if (act) {
+                mf[(size_t)ra * g.W + c] = ma;
+                argmax_merge(bv, bi, ma, ra * g.W + c);
+                cnt += (ma == ma && kbin(ma) == pred_bin) ? 1u : 0u;
+                low += (ma == ma && kbin(ma) < pred_bin) ? 1u : 0u;
+            }
+            if (has_b) {
+                mf[(size_t)rb * g.W + c] = mb;
+                argmax_merge(bv, bi, mb, rb * g.W + c);
+                cnt += (mb == mb && kbin(mb) == pred_bin) ? 1u : 0u;
+                low += (mb == mb && kbin(mb) < pred_bin) ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_down(bv, o, 64);
+            const int oi = __shfl_down(bi, o, 64);
+            argmax_merge(bv, bi, ov, oi);
+        }
+        const int lane = tidq & 63, wv = tidq >> 6;
+        unsigned incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) low += __shfl_down(low, o, 64);
+        if (lane == 0) {
+            sv[wv] = bv;
+            si[wv] = bi;
+            hl[WG / 64 + 1 + wv] = low;
+        }
+        if (lane == 63) hl[wv] = incl;
+        __syncthreads();
+        if (tidq == 0) {
+            for (int i = 1; i < WG / 64; ++i) argmax_merge(bv, bi, sv[i], si[i]);
+            part_val[(size_t)f * qpf + qi] = bv;
+            part_idx[(size_t)f * qpf + qi] = bi;
+            unsigned run = 0, lo = 0;
+            for (int i = 0; i < WG / 64; ++i) {
+                const unsigned t = hl[i];
+                hl[i] = run;
+                run += t;
+                lo += hl[WG / 64 + 1 + i];
+            }
+            unsigned base = 0;
+            if (selw && pred_bin) {
+                unsigned* sw = selw + (size_t)f * sel_stride;
+                if (lo) atomicAdd(&sw[1], lo);
+                if (run) {
+                    atomicAdd(&sw[2], run);
+                    base = atomicAdd(&sw[3], run);
+                }
+            }
+            hl[WG / 64] = base;
+        }
+        __syncthreads();
+        if (selw && pred_bin && cnt) {   // second walk over this lane's values: the bin's elements -> compact
+            float* dst = compact + (size_t)f * fpix + hl[WG / 64] + hl[wv] + (incl - cnt);
+            typename MX::template PosIter<L> p2(ltq);
+            for (int x = ltq; x < g.W; x += L) {
+                const float2 z = bufq[p2.pos()];
+                p2.up();
+                const float ma = fabsf(z.x * g.inv), mb = fabsf(z.y * g.inv);
+                if (act && ma == ma && kbin(ma) == pred_bin) *dst++ = ma;
+                if (has_b && mb == mb && kbin(mb) == pred_bin) *dst++ = mb;
+            }
+        }
+        __syncthreads();   // the row buffers and the bookkeeping words are free for the next quad
     }
 }
 
@@ -631,6 +839,93 @@ int wmr_rows_inv(const float2* T, float* out, const float2* twx, const float* am
         using MX = Mix3<A_, B_, C_, L_>;                                                                                                   \
         if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_inv<MX>, nquads, st, &lds, &grid))) return rc;                                          \
         hipLaunchKernelGGL((k_wmr_rows_inv<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, T, out, twx, amax, g, nframes, qpf);                 \
+    } break;
+        B4D_WMR_LENGTHS(X)
+#undef X
+        default: return fail(B4D_ESIZE, "no mixed-radix row kernel for this length");
+    }
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+// ---- general-size correlation on the same passes (b4d_track.hip, b4d_general.hip) -----------------------------------------
+static WmrGeom wmr_plain_geom(int ny, int nx) {
+    WmrGeom g{};
+    g.h = g.H = ny;
+    g.w = g.W = nx;
+    g.Wh = nx / 2 + 1;
+    g.Hp = wmr_pitch(ny);
+    g.hp = (ny + 1) / 2;
+    g.inv = 1.0f / ((float)ny * (float)nx);
+    return g;
+}
+
+size_t wmr_spectrum_elems(int ny, int nx) { return (size_t)(nx / 2 + 1) * wmr_pitch(ny); }
+
+int wmr_forward_spectra(const float* frames, int nframes, int ny, int nx, const float2* twx, const float2* twy, float2* S, float* scratch,
+                        hipStream_t st) {
+    const WmrGeom g = wmr_plain_geom(ny, nx);
+    int rc;
+    if ((rc = wmr_rows_fwd(frames, S, twx, scratch, g, nframes, st))) return rc;
+    return wmr_cols_launch<2>(S, nullptr, twy, nullptr, nullptr, g, nframes, nullptr, 0u, 0, st);
+}
+
+int wmr_product_inverse(const float2* A, const float2* B, const int* ia, const int* ib, int npairs, int ny, int nx, const float2* twy,
+                        float2* G, int whiten, float eps, unsigned flags, hipStream_t st) {
+    const WmrGeom g = wmr_plain_geom(ny, nx);
+    const unsigned grid = (unsigned)npairs * (unsigned)g.Wh;
+    switch (g.H) {
+#define X(N_, A_, B_, C_, L_)                                                                                                            \
+    case N_:                                                                                                                             \
+        if (whiten)                                                                                                                      \
+            hipLaunchKernelGGL((k_wmr_cols_prod<Mix3<A_, B_, C_, L_>, true>), dim3(grid), dim3(L_), 0, st, A, B, ia, ib, G, twy, g, eps, flags);  \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((k_wmr_cols_prod<Mix3<A_, B_, C_, L_>, false>), dim3(grid), dim3(L_), 0, st, A, B, ia, ib, G, twy, g, eps, flags); \
+        break;
+        B4D_WMR_LENGTHS(X)
+#undef X
+        default: return fail(B4D_ESIZE, "no mixed-radix column kernel for this length");
+    }
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int wmr_quads_per_frame(int ny) { return ((ny + 1) / 2 + WMR_Q - 1) / WMR_Q; }
+
+int wmr_rows_magnitude(const float2* G, int npairs, int ny, int nx, const float2* twx, float* mag, float* part_val, int* part_idx,
+                       unsigned* selw, int sel_stride, unsigned pred_bin, float* compact, hipStream_t st) {
+    const WmrGeom g = wmr_plain_geom(ny, nx);
+    const int qpf = wmr_quads_per_frame(ny), nquads = npairs * qpf;
+    size_t lds = 0;
+    int grid = 0, rc;
+    switch (g.W) {
+#define X(N_, A_, B_, C_, L_)                                                                                                       \
+    case N_: {                                                                                                                      \
+        using MX = Mix3<A_, B_, C_, L_>;                                                                                            \
+        if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_mag<MX>, nquads, st, &lds, &grid))) return rc;                                   \
+        hipLaunchKernelGGL((k_wmr_rows_mag<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, G, mag, part_val, part_idx, twx, g, npairs, qpf, \
+                           selw, sel_stride, pred_bin, compact);                                                                    \
+    } break;
+        B4D_WMR_LENGTHS(X)
+#undef X
+        default: return fail(B4D_ESIZE, "no mixed-radix row kernel for this length");
+    }
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int wmr_rows_real_out(const float2* G, int nframes, int ny, int nx, const float2* twx, float* out, hipStream_t st) {
+    const WmrGeom g = wmr_plain_geom(ny, nx);
+    const int qpf = wmr_quads_per_frame(ny), nquads = nframes * qpf;
+    size_t lds = 0;
+    int grid = 0, rc;
+    switch (g.W) {
+#define X(N_, A_, B_, C_, L_)                                                                                                             \
+    case N_: {                                                                                                                            \
+        using MX = Mix3<A_, B_, C_, L_>;                                                                                                  \
+        if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_out<MX>, nquads, st, &lds, &grid))) return rc;                                         \
+        hipLaunchKernelGGL((k_wmr_rows_out<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, G, (const float*)nullptr, out, (float*)nullptr,    \
+                           twx, (const float*)nullptr, g, nframes, qpf, 1.0f, 0u);                                                        \
     } break;
         B4D_WMR_LENGTHS(X)
 #undef X

@@ -33,4 +33,23 @@ int wmr_cols(float2* T, const float2* filt, const float2* twy, const float* pmax
 // T -> out (nframes, h, w): inverse row transforms, 1/(H W), normalise by max|frame|, clip, rescale, crop
 int wmr_rows_inv(const float2* T, float* out, const float2* twx, const float* amax, const WmrGeom& g, int nframes, hipStream_t st);
 
+// ---- general-size correlation (tracking, xcorr2d) on the same passes.  Spectra / G workspaces hold wmr_spectrum_elems(ny, nx)
+// complex words per item in the transposed [k][ky] layout.
+size_t wmr_spectrum_elems(int ny, int nx);
+int wmr_quads_per_frame(int ny);   // arg-max partials per map written by wmr_rows_magnitude
+// real frames (nframes, ny, nx) -> 2-D half spectra S; scratch: nframes * (ny + 1) / 2 floats
+int wmr_forward_spectra(const float* frames, int nframes, int ny, int nx, const float2* twx, const float2* twy, float2* S, float* scratch,
+                        hipStream_t st);
+// G[pair] = inverse column transforms of A[ia[pair]] conj(B[ib[pair]]) (whitened if `whiten`; DC zeroed with B4D_REMOVE_MEAN)
+int wmr_product_inverse(const float2* A, const float2* B, const int* ia, const int* ib, int npairs, int ny, int nx, const float2* twy,
+                        float2* G, int whiten, float eps, unsigned flags, hipStream_t st);
+// G -> |corr| maps (npairs, ny, nx), fftshift-ed, scaled 1/(ny nx), + wmr_quads_per_frame(ny) arg-max partials per map.
+// selw != null && pred_bin != 0: per map at selw + i * sel_stride, word 1 += values below the key bin pred_bin, word 2 += values
+// in it, word 3 = append cursor of compact + i * ny * nx, which receives the bin's values (the median's first select step,
+// b4d_track.hip; all zeroed by the caller)
+int wmr_rows_magnitude(const float2* G, int npairs, int ny, int nx, const float2* twx, float* mag, float* part_val, int* part_idx,
+                       unsigned* selw, int sel_stride, unsigned pred_bin, float* compact, hipStream_t st);
+// G -> real maps (nframes, ny, nx), fftshift-ed, scaled 1/(ny nx)
+int wmr_rows_real_out(const float2* G, int nframes, int ny, int nx, const float2* twx, float* out, hipStream_t st);
+
 }  // namespace b4d

@@ -211,7 +211,7 @@ def test_template_matching_batch_map_and_truth(gs):
         assert res[i, 2] == pytest.approx(float(corr.max()), abs=2e-4)
 
 
-@pytest.mark.parametrize("shape", [(200, 300), (171, 170), (600, 720)])
+@pytest.mark.parametrize("shape", [(200, 300), (171, 170), (600, 720), (720, 600), (720, 1280)])   # the last three: mixed-radix kernels
 def test_phase_correlation_general_sizes(gs, shape):
     """Phase correlation on frames that are not a power of two (DFT-matrix / fused mixed-radix plans) against the
     oracle: integer arg-max exact, sub-pixel shift / peak within the float32 bar of the power-of-two path."""
@@ -228,7 +228,9 @@ def test_phase_correlation_general_sizes(gs, shape):
         got = gs.phase_correlation(base[sl], fr, slices_yx=sl)
         wi = S.phase_correlation(base[sl], fr, slices_yx=sl, subpixel=False)
         gi = gs.phase_correlation(base[sl], fr, slices_yx=sl, subpixel=False)
-        assert (gi[0], gi[1]) == (wi[0], wi[1]) == (dy, dx)
+        assert (gi[0], gi[1]) == (wi[0], wi[1])            # integer output: equal to the reference's, whatever it finds
+        if shape[0] <= 600:                                # (on the 720-row crops the reference itself loses some of these
+            assert (gi[0], gi[1]) == (dy, dx)              #  61 / 41-px templates to noise: only parity is asserted there)
         assert got[0] == pytest.approx(want[0], abs=5e-3) and got[1] == pytest.approx(want[1], abs=5e-3)
         assert got[2] == pytest.approx(want[2], rel=1e-3) and got[3] == pytest.approx(want[3], rel=2e-3)
 

@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/r2t
-timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py tests/test_gpu_metrics.py -x -q -m gpu > gpurun_out/r2t/pytest.log 2>&1; tail -5 gpurun_out/r2t/pytest.log
-timeout -k 10 300 python tools/bench_configs.py 3 2>&1 | tail -1
-bash tools/prof_stats.sh r2t/cfg3 tools/bench_configs.py 3 > /dev/null; python3 tools/prof_summary.py gpurun_out/r2t/cfg3 > gpurun_out/r2t/s.txt; head -9 gpurun_out/r2t/s.txt
+mkdir -p gpurun_out/r2u
+timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py tests/test_gpu_signal.py tests/test_gpu_metrics.py -x -q -m gpu > gpurun_out/r2u/pytest.log 2>&1; tail -5 gpurun_out/r2u/pytest.log
+timeout -k 10 300 python tools/dev_general_track.py 2>&1 | tail -2
