@@ -284,7 +284,9 @@ def main():
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         # one process per GPU; RCCL ("nccl") carries device collectives (the cfg4 all-reduce; the cfg2 data path has none:
         # frames are sharded, nothing is exchanged), gloo carries the host-side barrier and the max-over-ranks of the timing
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl")
+        # B4D_BENCH_BACKEND=gloo: rehearsal of the N > 1 logic with several ranks on ONE GPU (RCCL refuses duplicate devices);
+        # never set by the driver
+        dist.init_process_group(backend=os.environ.get("B4D_BENCH_BACKEND", "cpu:gloo,cuda:nccl"))
 
     from barc4dip_amd import _ffi, synth
 
@@ -346,8 +348,11 @@ def main():
         if world == 1:
             del stack
             torch.cuda.empty_cache()
-            secondary["cfg3"] = secondary_cfg3(torch, cpu)
-            secondary["cfg5"] = secondary_cfg5(torch, cpu)
+            for name, fn in (("cfg3", secondary_cfg3), ("cfg5", secondary_cfg5)):
+                try:
+                    secondary[name] = fn(torch, cpu)
+                except Exception as e:      # a secondary leg never takes the headline line down with it
+                    secondary[name] = {"error": repr(e)}
         else:
             secondary["cfg3"] = secondary["cfg5"] = "measured at --gpus 1 only (frames are sharded, no collective: N ranks run N copies)"
 
