@@ -87,6 +87,12 @@ k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, float* __rest
     const int pair = blockIdx.x * SEQ + seq;
     const bool live = 2 * pair < ny;  // ragged last workgroup: idle transforms still take part in the barriers
     const size_t frame = blockIdx.y;
+    if (SRC) {   // rows outside the ROI are zero: a workgroup without a ROI row writes NOTHING -- the column pass and k_nyq
+                 // know the ROI rows (ColArgs::srcs / NyqArgs::srcs) and never read the others (a 121-px template in a
+                 // 1024^2 frame: 88 % of the half spectrum is neither written here nor read there)
+        const int wa = 2 * blockIdx.x * SEQ, wb = wa + 2 * SEQ;
+        if (wb <= srcs[frame].y0 || wa >= srcs[frame].y1) return;
+    }
     float2* lds = lds_all + seq * G::LDS_ELEMS;
     float2 v[E];
     if (!live) {
@@ -151,6 +157,8 @@ struct ColArgs {
     int nx;
     unsigned flags;
     int half_rows;    // COL_PSD_AC: the consumer uses R[-y,-x] = R[y,x]: only rows 0..ny/2+1 of the tile are stored
+    const RowSrc* srcs;  // COL_FORWARD, optional: item i holds data in rows [srcs[i].y0, srcs[i].y1) only (zero-embedded ROI);
+                         // the other rows are taken as zero WITHOUT being read (k_row_r2c does not write them)
 #ifdef B4D_DIAG
     unsigned long long* diag;  // diagnostic build only: 8 s_memtime stamps per workgroup
 #endif
@@ -240,13 +248,27 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
     B4D_STAMP(0);
     // column pairs in issue order: the first pair's loads complete first, so its butterflies start while the
     // second pair is still streaming in (loads return in order; the compiler's counted vmcnt does the rest)
+    int ry0 = 0, ry1 = NY;
+    if (MODE == COL_FORWARD && p.srcs) {
+        ry0 = p.srcs[fr].y0;
+        ry1 = p.srcs[fr].y1;
+    }
 #pragma unroll
     for (int h = 0; h < NC / 2; ++h) {
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const float4 q = *reinterpret_cast<const float4*>(tile + (size_t)(T * j * CT) + toff + 2 * h);
-            v[2 * h][j] = make_float2(q.x, q.y);
-            v[2 * h + 1][j] = make_float2(q.z, q.w);
+            if (MODE == COL_FORWARD) {   // clamped row + select: the load stays unconditional (no branch per load), rows outside the
+                                         // ROI re-read a ROI row that other lanes fetch anyway
+                const int ky = u + T * j, kc = min(max(ky, ry0), ry1 - 1);
+                float4 q = *reinterpret_cast<const float4*>(tile + (size_t)kc * CT + NC * cpm + 2 * h);
+                if (ky < ry0 || ky >= ry1) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                v[2 * h][j] = make_float2(q.x, q.y);
+                v[2 * h + 1][j] = make_float2(q.z, q.w);
+            } else {
+                const float4 q = *reinterpret_cast<const float4*>(tile + (size_t)(T * j * CT) + toff + 2 * h);
+                v[2 * h][j] = make_float2(q.x, q.y);
+                v[2 * h + 1][j] = make_float2(q.z, q.w);
+            }
         }
     }
     B4D_DRAIN();
@@ -420,6 +442,7 @@ struct NyqArgs {
     const float2* tw;
     float psd_scale, eps;
     int nx, items;
+    const RowSrc* srcs;  // NYQ_FORWARD, optional: rows outside [srcs[i].y0, srcs[i].y1) are zero and were not written by k_row_r2c
 };
 
 // grid (ceil(items/SEQ)), block T*SEQ: one length-NY transform per T lanes.
@@ -449,8 +472,16 @@ __global__ void __launch_bounds__((NY / E16) * SEQ) k_nyq(NyqArgs p) {
         }
         return;
     }
+    int ry0 = 0, ry1 = NY;
+    if (MODE == NYQ_FORWARD && p.srcs) {
+        ry0 = p.srcs[it].y0;
+        ry1 = p.srcs[it].y1;
+    }
 #pragma unroll
-    for (int j = 0; j < E; ++j) v[j] = make_float2(p.rows[it * NY + u + T * j], 0.f);
+    for (int j = 0; j < E; ++j) {
+        const int ky = u + T * j;
+        v[j] = make_float2((ky >= ry0 && ky < ry1) ? p.rows[it * NY + ky] : 0.f, 0.f);
+    }
     Fft3<G, 1>::run(v, v, u, 0, lds, p.tw);
     if (MODE == NYQ_FORWARD) {
         if (live) {

@@ -702,10 +702,12 @@ static int forward_spectra(const b4d_plan* pl, const float* frames, const RowSrc
     ca.spec = spec;
     ca.tw = pl->tw_y;
     ca.nx = pl->nx;
+    ca.srcs = srcs;    // zero-embedded ROIs: only the ROI rows exist in `spec` / `nyq_rows`
     if ((rc = dispatch_col<COL_FORWARD>(pl, ca, items, st))) return rc;
     NyqArgs na{};
     na.rows = nyq_rows;
     na.f_out = nyq;
+    na.srcs = srcs;
     return dispatch_nyq<NYQ_FORWARD>(pl, na, items, st);
 }
 

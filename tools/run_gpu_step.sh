@@ -1,9 +1,5 @@
-mkdir -p gpurun_out/r2v
-export B4D_BENCH_BACKEND=gloo
-timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 1 > gpurun_out/r2v/bench2.json 2> gpurun_out/r2v/bench2.err; echo "rc $?"
-tail -5 gpurun_out/r2v/bench2.err
-python - <<'PY'
-import json
-l=json.loads(open("gpurun_out/r2v/bench2.json").read().strip().splitlines()[-1])
-print(l["n_gpus"], l["value"]); print(json.dumps(l["secondary"], indent=1)[:1500])
-PY
+mkdir -p gpurun_out/r2x
+timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py tests/test_gpu_metrics.py tests/test_gpu_signal.py -x -q -m gpu > gpurun_out/r2x/pytest.log 2>&1; tail -4 gpurun_out/r2x/pytest.log
+timeout -k 10 300 python tools/bench_configs.py 3 2>&1 | tail -1
+bash tools/prof_stats.sh r2x/cfg3 tools/bench_configs.py 3 > /dev/null; python3 tools/prof_summary.py gpurun_out/r2x/cfg3 > gpurun_out/r2x/s.txt; head -7 gpurun_out/r2x/s.txt
+timeout -k 10 200 python tools/dev_soak_track.py 11 2>&1 | tail -1
