@@ -622,6 +622,10 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
     // ---- C2R_MAG
     float bv = -1.0f;
     int bi = 0x7fffffff;
+    // expected-median-bin bookkeeping (selw != null): per value one shift and two compares next to the store; bit j / 16 + j of
+    // `hits` = value j of row a / b is in the bin (magnitudes are >= 0: the key's top 11 bits are 1024 + (bits >> 21))
+    const unsigned pbx = (p.selw && p.pred_bin >= 1024u) ? p.pred_bin - 1024u : 0xffffffffu;
+    unsigned cnt = 0, low = 0, hits = 0;
     if (live) {
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -631,7 +635,13 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
             o1[c] = m1;
             argmax_merge(bv, bi, m0, ra * NX + c);
             argmax_merge(bv, bi, m1, rb * NX + c);
+            if (pbx != 0xffffffffu) {
+                const unsigned b0 = m0 == m0 ? __float_as_uint(m0) >> 21 : 0xfffffffeu, b1 = m1 == m1 ? __float_as_uint(m1) >> 21 : 0xfffffffeu;
+                hits |= (b0 == pbx ? 1u : 0u) << j | (b1 == pbx ? 1u : 0u) << (16 + j);
+                low += (b0 < pbx ? 1u : 0u) + (b1 < pbx ? 1u : 0u);
+            }
         }
+        cnt = __popc(hits);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -657,19 +667,6 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
         // counts of the magnitudes below / inside the expected median bin and the bin's elements themselves: lane counts,
         // a workgroup scan, THREE global atomics per workgroup (no per-element atomics, no second read of the map)
         constexpr int NW = (T * SEQ + 63) / 64;
-        const unsigned pb = p.pred_bin;
-        unsigned cnt = 0, low = 0;
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < E; ++j) {
-                const float m0 = fabsf(v[j].y * p.scale), m1 = fabsf(v[j].x * p.scale);
-                const unsigned b0 = (__float_as_uint(m0) | 0x80000000u) >> 21, b1 = (__float_as_uint(m1) | 0x80000000u) >> 21;   // f2key(x >= 0) >> 21
-                cnt += (m0 == m0 && b0 == pb) ? 1u : 0u;
-                cnt += (m1 == m1 && b1 == pb) ? 1u : 0u;
-                low += (m0 == m0 && b0 < pb) ? 1u : 0u;
-                low += (m1 == m1 && b1 < pb) ? 1u : 0u;
-            }
-        }
         unsigned incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -695,17 +692,27 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
             if (lo) atomicAdd(&sw[1], lo);
             if (run) atomicAdd(&sw[2], run);
             hl[NW] = run ? atomicAdd(&sw[3], run) : 0u;
+            hl[2 * NW + 1] = run;
         }
         __syncthreads();
+        // The bin's elements go through the (free) exchange buffer: masked 4-byte LDS writes at the lane's offset, then one
+        // coalesced copy to `compact` -- appended straight to global memory they cost as many (mostly empty) store
+        // instructions as the map itself (+34 % on this kernel).
+        constexpr int STAGE_WORDS = 2 * E * T * SEQ;   // every value of the workgroup may be in the bin
+        static_assert(sizeof(lds_all) >= sizeof(unsigned) * (64 + 2 * NW + 2 + STAGE_WORDS), "exchange buffer too small for the staging");
+        float* stg = reinterpret_cast<float*>(hl + 2 * NW + 2);
         if (cnt) {
-            float* dst = p.compact + frame * (size_t)ny * NX + hl[NW] + hl[w] + (incl - cnt);
+            float* q = stg + hl[w] + (incl - cnt);
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const float m0 = fabsf(v[j].y * p.scale), m1 = fabsf(v[j].x * p.scale);
-                if (m0 == m0 && ((__float_as_uint(m0) | 0x80000000u) >> 21) == pb) *dst++ = m0;
-                if (m1 == m1 && ((__float_as_uint(m1) | 0x80000000u) >> 21) == pb) *dst++ = m1;
+                if (hits & (1u << j)) *q++ = fabsf(v[j].y * p.scale);
+                if (hits & (1u << (16 + j))) *q++ = fabsf(v[j].x * p.scale);
             }
         }
+        __syncthreads();
+        const unsigned total = hl[2 * NW + 1];
+        float* dst = p.compact + frame * (size_t)ny * NX + hl[NW];
+        for (unsigned i = threadIdx.x; i < total; i += T * SEQ) dst[i] = stg[i];
     }
 }
 

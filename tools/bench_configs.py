@@ -96,6 +96,10 @@ def cfg5(T=32, n=4096, sigma=1.5, steps=3):   # T = 32 on one GPU
 
 
 if __name__ == "__main__":
+    import os
+    if os.environ.get("B4D_NOPRED"):   # dev: time the fallback route of the tracker's median (no expected-bin gathering)
+        from barc4dip_amd import _ffi
+        _ffi.lib().b4d_set_option(b"track_predict_bin", 0)
     which = sys.argv[1:] or ["3", "4", "5"]
     if "3" in which:
         cfg3()

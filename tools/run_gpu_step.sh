@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r2y
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r2y/pytest.log 2>&1; tail -3 gpurun_out/r2y/pytest.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r2y/bench.json 2> gpurun_out/r2y/bench.err; echo "bench rc $?"
+mkdir -p gpurun_out/r2z
+timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py tests/test_gpu_metrics.py -x -q -m gpu > gpurun_out/r2z/pytest.log 2>&1; tail -3 gpurun_out/r2z/pytest.log
+timeout -k 10 300 python tools/bench_configs.py 3 2>&1 | tail -1
+bash tools/prof_stats.sh r2z/cfg3b tools/bench_configs.py 3 > /dev/null; python3 tools/prof_summary.py gpurun_out/r2z/cfg3b > gpurun_out/r2z/s.txt; head -4 gpurun_out/r2z/s.txt
