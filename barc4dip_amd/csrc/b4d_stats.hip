@@ -79,7 +79,11 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* sh /* [16*K] *
 }
 
 // ------------------------------------------------------------------------------------ temporal
-// One lane owns 4 adjacent pixels (one 16-B load per frame); frames are walked with 4 loads in flight.
+// One lane owns 4 adjacent pixels (one 16-B load per frame); frames are walked with TU loads in flight.
+#ifndef B4D_TACC_UNROLL
+#define B4D_TACC_UNROLL 4
+#endif
+constexpr int TU = B4D_TACC_UNROLL;
 __global__ void __launch_bounds__(256) k_temporal_acc(const float* __restrict__ frames, int nframes, size_t npix,
                                                       double* __restrict__ sx, double* __restrict__ sxx) {
     const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -88,12 +92,12 @@ __global__ void __launch_bounds__(256) k_temporal_acc(const float* __restrict__ 
     if (i4 + 3 < npix) {
         const float* p = frames + i4;
         int t = 0;
-        for (; t + 4 <= nframes; t += 4) {
-            float4 v[4];
+        for (; t + TU <= nframes; t += TU) {
+            float4 v[TU];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(p + (size_t)(t + k) * npix);
+            for (int k = 0; k < TU; ++k) v[k] = *reinterpret_cast<const float4*>(p + (size_t)(t + k) * npix);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < TU; ++k) {
                 const double x0 = v[k].x, x1 = v[k].y, x2 = v[k].z, x3 = v[k].w;
                 a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3;
                 q[0] = fma(x0, x0, q[0]); q[1] = fma(x1, x1, q[1]); q[2] = fma(x2, x2, q[2]); q[3] = fma(x3, x3, q[3]);

@@ -1,7 +1,2 @@
-mkdir -p gpurun_out/r3a
-bash tools/prof_stats.sh r3a/cfg3 tools/bench_configs.py 3 > /dev/null; python3 tools/prof_summary.py gpurun_out/r3a/cfg3 > gpurun_out/r3a/cfg3_summary.txt; head -8 gpurun_out/r3a/cfg3_summary.txt
-bash tools/pmc_tool.sh r3a/cfg3_fetch tools/bench_configs.py 3 -- FETCH_SIZE | cut -c1-200
-bash tools/pmc_tool.sh r3a/cfg3_write tools/bench_configs.py 3 -- WRITE_SIZE | cut -c1-200
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r3a/bench_full -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/r3a/bench_full.json 2> $GRAFT_REPO_ROOT/gpurun_out/r3a/bench_full.err
-cd $GRAFT_REPO_ROOT; python3 tools/prof_summary.py gpurun_out/r3a/bench_full | head -20
+mkdir -p gpurun_out/r3b
+timeout -k 10 900 python -m pytest tests/test_gpu_metrics.py -x -q -m gpu -k "detector_format or default_tracker" > gpurun_out/r3b/pytest.log 2>&1; tail -12 gpurun_out/r3b/pytest.log
