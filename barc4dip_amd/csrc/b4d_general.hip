@@ -384,6 +384,16 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
 
 int general_fft2d(b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
+    if (pl->large && wmr_supported(nx) && wmr_supported(ny)) {   // mixed-radix kernels on both sides (b4d_wiener_mr.hip)
+        const size_t selems = wmr_spectrum_elems(ny, nx);
+        for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
+            const int nb = std::min(pl->chunk, batch - b0);
+            int rc = wmr_fft2d(frames + (size_t)b0 * npix, nb, ny, nx, pl->tw_x, pl->tw_y, pl->gbuf1,
+                               reinterpret_cast<float*>(pl->gbuf1 + selems * nb), out + (size_t)b0 * npix, st);
+            if (rc) return rc;
+        }
+        return B4D_OK;
+    }
     for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
         const int nb = std::min(pl->chunk, batch - b0);
         int rc = dft2(pl, frames + (size_t)b0 * npix, true, nb, 0, pl->gbuf1, pl->gbuf2, st);

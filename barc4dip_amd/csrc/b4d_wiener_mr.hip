@@ -572,6 +572,56 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_mag(const float2*
     }
 }
 
+// fft2d of real frames at general sizes (signal/fft.py:198-237): the 2-D half spectrum S[k][ky] (k_wmr_cols<., 2>) -> the full
+// fftshift-ed complex spectrum (nframes, H, W): every quad gathers its 8 rows ky as 64-byte pieces, stages them through the row
+// buffers and writes, per row, the direct half (ky, kx) and the conjugate mirror (-ky, -kx) along kx.
+template <class MX>
+__global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_spec(const float2* __restrict__ S, float2* __restrict__ out, WmrGeom g,
+                                                                     int nframes, int qpf) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr int L = MX::LANES;
+    static_assert(MX::BUF >= MX::N + 2, "row buffer too small to stage two half rows");
+    const int tid = threadIdx.x, lt = tid % L, sub = tid / L;
+    const int qpf2 = (qpf + 1) & ~1, nitems = (nframes * qpf2 + 15) & ~15;
+    auto next_item = [&](int j) {
+        for (j += gridDim.x; j < nitems && !quad_of(j, qpf, qpf2, nframes).valid; j += gridDim.x) {}
+        return j;
+    };
+    const size_t fpix = (size_t)g.H * g.W;
+    for (int q = next_item((int)blockIdx.x - (int)gridDim.x); q < nitems; q = next_item(q)) {
+        const QuadRef qr = quad_of(q, qpf, qpf2, nframes);
+        const int f = qr.f, qi = qr.qi;
+        {
+            const int j = tid & (WMR_Q - 1), kk = tid / WMR_Q, pj = WMR_Q * qi + j;
+            float2* bj = sm + (size_t)j * MX::BUF;
+            const float2* src = S + (size_t)f * g.Wh * g.Hp + 2 * min(pj, g.hp - 1);
+            for (int k = kk; k < g.Wh; k += L) {
+                const float4 p = *reinterpret_cast<const float4*>(src + (size_t)k * g.Hp);
+                bj[k] = make_float2(p.x, p.y);
+                bj[g.Wh + k] = make_float2(p.z, p.w);
+            }
+        }
+        __syncthreads();
+        const int pr = WMR_Q * qi + sub;
+        const float2* mine = sm + (size_t)sub * MX::BUF;
+        float2* of = out + (size_t)f * fpix;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ky = 2 * pr + e;
+            if (pr >= g.hp || ky >= g.H) continue;
+            float2* drow = of + (size_t)((ky + g.H / 2) % g.H) * g.W;
+            float2* mrow = of + (size_t)(((g.H - ky) % g.H + g.H / 2) % g.H) * g.W;
+            const float2* prow = mine + e * g.Wh;
+            for (int kx = lt; kx < g.Wh; kx += L) {
+                const float2 v = prow[kx];
+                drow[(kx + g.W / 2) % g.W] = v;
+                if (kx > 0 && 2 * kx != g.W) mrow[(g.W - kx + g.W / 2) % g.W] = make_float2(v.x, -v.y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Zero-lag value of the (unscaled) autocorrelation of every frame from the column-inverted half spectrum G = T[k][y]:
 // R[0,0] = sum over the FULL kx range of G[kx][0] = G[0] + 2 sum Re G[k] (+ G[W/2] for even W).  grid (nframes), block 256
 __global__ void __launch_bounds__(256) k_wmr_peak(const float2* __restrict__ T, WmrGeom g, float* __restrict__ peak) {
@@ -926,6 +976,29 @@ int wmr_rows_real_out(const float2* G, int nframes, int ny, int nx, const float2
         if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_out<MX>, nquads, st, &lds, &grid))) return rc;                                         \
         hipLaunchKernelGGL((k_wmr_rows_out<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, G, (const float*)nullptr, out, (float*)nullptr,    \
                            twx, (const float*)nullptr, g, nframes, qpf, 1.0f, 0u);                                                        \
+    } break;
+        B4D_WMR_LENGTHS(X)
+#undef X
+        default: return fail(B4D_ESIZE, "no mixed-radix row kernel for this length");
+    }
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+
+int wmr_fft2d(const float* frames, int nframes, int ny, int nx, const float2* twx, const float2* twy, float2* S, float* scratch,
+              float2* out, hipStream_t st) {
+    int rc = wmr_forward_spectra(frames, nframes, ny, nx, twx, twy, S, scratch, st);
+    if (rc) return rc;
+    const WmrGeom g = wmr_plain_geom(ny, nx);
+    const int qpf = wmr_quads_per_frame(ny), nquads = nframes * qpf;
+    size_t lds = 0;
+    int grid = 0;
+    switch (g.W) {
+#define X(N_, A_, B_, C_, L_)                                                                                                  \
+    case N_: {                                                                                                                 \
+        using MX = Mix3<A_, B_, C_, L_>;                                                                                       \
+        if ((rc = wmr_rows_launch<MX>(&k_wmr_rows_spec<MX>, nquads, st, &lds, &grid))) return rc;                             \
+        hipLaunchKernelGGL((k_wmr_rows_spec<MX>), dim3(grid), dim3(WMR_Q* L_), lds, st, (const float2*)S, out, g, nframes, qpf); \
     } break;
         B4D_WMR_LENGTHS(X)
 #undef X

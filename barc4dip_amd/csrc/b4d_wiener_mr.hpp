@@ -49,6 +49,9 @@ int wmr_product_inverse(const float2* A, const float2* B, const int* ia, const i
 // b4d_track.hip; all zeroed by the caller)
 int wmr_rows_magnitude(const float2* G, int npairs, int ny, int nx, const float2* twx, float* mag, float* part_val, int* part_idx,
                        unsigned* selw, int sel_stride, unsigned pred_bin, float* compact, hipStream_t st);
+// fft2d of real frames: out (nframes, ny, nx) complex, fftshift-ed (signal/fft.py:198-237); S / scratch as wmr_forward_spectra
+int wmr_fft2d(const float* frames, int nframes, int ny, int nx, const float2* twx, const float2* twy, float2* S, float* scratch,
+              float2* out, hipStream_t st);
 // G -> real maps (nframes, ny, nx), fftshift-ed, scaled 1/(ny nx)
 int wmr_rows_real_out(const float2* G, int nframes, int ny, int nx, const float2* twx, float* out, hipStream_t st);
 
