@@ -174,7 +174,11 @@ struct ColArgs {
         __builtin_amdgcn_sched_barrier(0);                                                        \
         if (p.diag && threadIdx.x == 0) p.diag[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = t__; \
     } while (0)
+#ifdef B4D_DIAG_DRAIN   // additionally separate issue from completion (perturbs the kernel: every phase waits for its memory traffic)
 #define B4D_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define B4D_DRAIN() do {} while (0)
+#endif
 #else
 #define B4D_STAMP(i) do {} while (0)
 #define B4D_DRAIN() do {} while (0)
