@@ -9,7 +9,8 @@ sys.path.insert(0, ".")
 from barc4dip_amd import _ffi, synth  # noqa: E402
 
 lib = _ffi.load_library("barc4dip_amd/csrc/libb4d_diag.so")
-T, n, chunk = 64, 2048, 64
+T = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
+n, chunk = 2048, 64
 stack = synth.speckle_stack_device(T, n)
 psd = torch.empty_like(stack)
 ac = torch.empty_like(stack)
