@@ -226,7 +226,7 @@ def test_general_lengths_vs_oracle(gs, shape):
     assert ac[shape[0] // 2, shape[1] // 2] == 1.0 and int(np.argmax(ac)) == (shape[0] // 2) * shape[1] + shape[1] // 2
 
 
-@pytest.mark.parametrize("shape", [(600, 600), (720, 1280), (1000, 2048), (513, 300), (2160, 2560)])
+@pytest.mark.parametrize("shape", [(600, 600), (720, 1280), (1000, 2048), (513, 300), (2160, 2560), (264, 520), (520, 264)])
 def test_large_general_lengths_vs_oracle(gs, shape):
     """Sides beyond the DFT-matrix range that split as 2^k * A * B (detector formats such as 2560 x 2160): fused
     in-LDS mixed-radix transform, rows / transpose / columns.  Same 1e-5 bar as the power-of-two kernels."""
@@ -244,8 +244,17 @@ def test_large_general_lengths_vs_oracle(gs, shape):
     assert ac[shape[0] // 2, shape[1] // 2] == 1.0 and int(np.argmax(ac)) == (shape[0] // 2) * shape[1] + shape[1] // 2
     st = np.stack([img, b, img[::-1].copy()])
     p3 = gs.psd2d_stack(st)
+    f3 = gs.fft2d_stack(st)
     for i in range(3):
         assert np.array_equal(p3[i], gs.psd2d(st[i])[0])
+        assert np.array_equal(f3[i], gs.fft2d(st[i])[0])
+    # full spectrum of a real frame: Hermitian in the shifted layout, F[-ky, -kx] = conj(F[ky, kx]) bit for bit (one value, two stores)
+    F = gs.fft2d(img)[0]
+    cy, cx = shape[0] // 2, shape[1] // 2
+    ys = (2 * cy - np.arange(shape[0])) % shape[0] if shape[0] % 2 == 0 else shape[0] - 1 - np.arange(shape[0])
+    xs = (2 * cx - np.arange(shape[1])) % shape[1] if shape[1] % 2 == 0 else shape[1] - 1 - np.arange(shape[1])
+    inner = np.ix_(np.arange(shape[0])[1:], np.arange(shape[1])[1:])   # row / column 0 of an even side hold the unpaired Nyquist bins
+    assert nerr(F[inner], np.conj(F[np.ix_(ys, xs)])[inner]) < 1e-6
 
 
 @pytest.mark.parametrize("name", ["f64_24x32", "f32_32x16", "f64_17x23"])

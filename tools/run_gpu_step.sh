@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r7
-B4D_LIB=barc4dip_amd/csrc/libb4d_ALIGNED_MIRROR.so timeout -k 10 300 python tools/dev_colseg.py 2048 > gpurun_out/r7/colseg_am.log 2>&1; cat gpurun_out/r7/colseg_am.log
+mkdir -p gpurun_out/r8
+timeout -k 10 900 python -m pytest tests/test_gpu_signal.py -x -q -m gpu > gpurun_out/r8/pytest.log 2>&1; tail -15 gpurun_out/r8/pytest.log
