@@ -757,14 +757,46 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_out(const float2*
 // ---- instantiated lengths -----------------------------------------------------------------------------------------
 //   4104 = 4096 + 8 (sigma 1.5 on 4k frames), 520 = 512 + 8, 264 = 256 + 8: Wiener padded sizes;
 //   2560 x 2160 (sCMOS), 1280 x 720, 600: general-size fft -> psd -> autocorr (b4d_general.hip)
+//   the other entries: sides of common area detectors / cameras and the powers of two that occur beside them in non-square
+//   formats (1024 x 768, 2448 x 2048, 4096 x 3000 ...); radices are picked for one round of every stage where the lanes allow
 #define B4D_WMR_LENGTHS(X)       \
     X(4104, 8, 27, 19, 256)      \
+    X(4096, 16, 16, 16, 256)     \
+    X(3840, 16, 16, 15, 256)     \
+    X(3648, 16, 12, 19, 256)     \
+    X(3200, 16, 20, 10, 256)     \
+    X(3072, 16, 16, 12, 256)     \
+    X(3000, 15, 10, 20, 256)     \
+    X(2592, 16, 18, 9, 256)      \
     X(2560, 16, 16, 10, 256)     \
+    X(2448, 16, 9, 17, 256)      \
+    X(2400, 16, 15, 10, 256)     \
+    X(2304, 16, 16, 9, 256)      \
     X(2160, 16, 27, 5, 256)      \
+    X(2048, 16, 16, 8, 256)      \
+    X(1944, 8, 27, 9, 256)       \
+    X(1936, 16, 11, 11, 256)     \
+    X(1920, 16, 12, 10, 256)     \
+    X(1600, 16, 10, 10, 128)     \
+    X(1536, 16, 16, 6, 128)      \
+    X(1440, 12, 12, 10, 128)     \
     X(1280, 16, 16, 5, 128)      \
+    X(1216, 16, 4, 19, 128)      \
+    X(1200, 10, 12, 10, 128)     \
+    X(1080, 12, 10, 9, 128)      \
+    X(1024, 16, 8, 8, 128)       \
+    X(1000, 10, 10, 10, 128)     \
+    X(960, 16, 12, 5, 128)       \
+    X(800, 16, 10, 5, 128)       \
+    X(768, 8, 8, 12, 64)         \
     X(720, 16, 9, 5, 64)         \
+    X(640, 16, 8, 5, 64)         \
     X(600, 8, 15, 5, 64)         \
+    X(576, 16, 6, 6, 64)         \
+    X(540, 12, 9, 5, 64)         \
     X(520, 8, 5, 13, 128)        \
+    X(512, 8, 8, 8, 64)          \
+    X(480, 8, 6, 10, 64)         \
     X(264, 8, 3, 11, 64)
 
 bool wmr_supported(int n) {

@@ -257,6 +257,29 @@ def test_large_general_lengths_vs_oracle(gs, shape):
     assert nerr(F[inner], np.conj(F[np.ix_(ys, xs)])[inner]) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (540, 960), (576, 768), (512, 800), (1000, 1024), (1080, 1920), (1200, 1600),
+                                   (1216, 1936), (1440, 2304), (1536, 2048), (1944, 2592), (2400, 3200), (2448, 3072),
+                                   (3000, 4096), (3648, 3840)])
+def test_detector_formats_mixed_radix(gs, shape):
+    """Every length of the mixed-radix table (csrc/b4d_wiener_mr.hip: B4D_WMR_LENGTHS) that the tests above do not reach, once
+    as a row length or a column length: camera / detector sides (1080 x 1920, 1200 x 1600, 1216 x 1936, 1944 x 2592, 2448 ...)
+    and the powers of two next to them.  fft2d, psd2d, autocorr2d, xcorr2d against the float64 oracle at the 1e-5 bar."""
+    from oracle import signal_np as S
+
+    rng = np.random.default_rng(shape[0] * 5 + shape[1])
+    img = (rng.poisson(150.0, size=shape) + 3 * rng.random(shape)).astype(np.float32)
+    b = (np.roll(img, (-4, 7), axis=(0, 1)) * 1.1 + rng.random(shape)).astype(np.float32)
+    r64 = img.astype(np.float64)
+    assert nerr(gs.fft2d(img)[0], S.fft2d(r64)[0]) < TOL
+    assert nerr(gs.psd2d(img)[0], S.psd2d(r64)[0]) < TOL
+    ac = gs.autocorr2d(img)[0]
+    assert nerr(ac, S.autocorr2d(r64)[0]) < TOL
+    assert ac[shape[0] // 2, shape[1] // 2] == 1.0 and int(np.argmax(ac)) == (shape[0] // 2) * shape[1] + shape[1] // 2
+    xc = gs.xcorr2d(img, b)[0]
+    assert nerr(xc, np.real(S.xcorr2d(r64, b.astype(np.float64))[0])) < TOL
+    assert np.unravel_index(int(np.argmax(np.abs(xc))), shape) == (shape[0] // 2 + 4, shape[1] // 2 - 7)
+
+
 @pytest.mark.parametrize("name", ["f64_24x32", "f32_32x16", "f64_17x23"])
 def test_golden_reference_vectors_small(gs, golden, name):
     """The small dense cases captured from the REAL reference (odd, non-square, float64 inputs)."""

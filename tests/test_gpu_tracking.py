@@ -211,7 +211,7 @@ def test_template_matching_batch_map_and_truth(gs):
         assert res[i, 2] == pytest.approx(float(corr.max()), abs=2e-4)
 
 
-@pytest.mark.parametrize("shape", [(200, 300), (171, 170), (600, 720), (720, 600), (720, 1280)])   # the last three: mixed-radix kernels
+@pytest.mark.parametrize("shape", [(200, 300), (171, 170), (600, 720), (720, 600), (720, 1280), (1080, 1920)])   # the last four: mixed-radix kernels
 def test_phase_correlation_general_sizes(gs, shape):
     """Phase correlation on frames that are not a power of two (DFT-matrix / fused mixed-radix plans) against the
     oracle: integer arg-max exact, sub-pixel shift / peak within the float32 bar of the power-of-two path."""

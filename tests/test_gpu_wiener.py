@@ -34,6 +34,23 @@ def test_wiener_vs_oracle(pp, shape, sigma, clip):
     assert float(np.max(np.abs(got - ref))) < 2e-5 * float(np.max(np.abs(img)))
 
 
+def test_wiener_detector_format(pp):
+    """A non-square camera format on the three-kernel route: 1072 x 1912, sigma 1.5 -> padded 1080 x 1920 (12 * 10 * 9 and
+    16 * 12 * 10), and a stack call against the per-frame calls."""
+    import torch
+    from oracle import wiener_np as W
+
+    img = synth.speckle_frame(2048, 21)[:1072, :1912].copy()
+    ref = W.deconvolve_psf(img, sigma=1.5)
+    got = pp.deconvolve_psf(img, sigma=1.5)
+    assert got.shape == img.shape and got.dtype == np.float32
+    assert float(np.max(np.abs(got - ref))) < 2e-5 * float(np.max(np.abs(img)))
+    st = np.stack([img, img[::-1].copy(), img[:, ::-1].copy(), img * 0.5, img + 7])
+    out = pp.deconvolve_psf(torch.from_numpy(st).cuda(), sigma=1.5, return_tensors=True).cpu().numpy()
+    for i in range(len(st)):
+        assert np.array_equal(out[i], pp.deconvolve_psf(st[i], sigma=1.5))
+
+
 @pytest.mark.parametrize("clip", [True, False])
 def test_cfg5_size(pp, clip):
     """BASELINE.json config 5 at its stated size: one 4096 x 4096 frame, sigma 1.5 (9 x 9 PSF, padded 4104 = 8 * 27 * 19),

@@ -93,6 +93,8 @@ int main() {
     worst = std::max(worst, check_radix<15>());
     worst = std::max(worst, check_radix<17>());
     worst = std::max(worst, check_radix<19>());
+    worst = std::max(worst, check_radix<18>());
+    worst = std::max(worst, check_radix<20>());
     worst = std::max(worst, check_radix<22>());
     worst = std::max(worst, check_radix<24>());
     worst = std::max(worst, check_radix<25>());
@@ -104,6 +106,36 @@ int main() {
     worst = std::max(worst, check_mix<Mix3<8, 3, 11, 128>>());
     worst = std::max(worst, check_mix<Mix3<16, 27, 5, 256>>());
     worst = std::max(worst, check_mix<Mix3<16, 16, 10, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 16, 16, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 16, 15, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 12, 19, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 20, 10, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 16, 12, 256>>());
+    worst = std::max(worst, check_mix<Mix3<15, 10, 20, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 18, 9, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 9, 17, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 15, 10, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 16, 9, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 16, 8, 256>>());
+    worst = std::max(worst, check_mix<Mix3<8, 27, 9, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 11, 11, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 12, 10, 256>>());
+    worst = std::max(worst, check_mix<Mix3<16, 10, 10, 128>>());
+    worst = std::max(worst, check_mix<Mix3<16, 16, 6, 128>>());
+    worst = std::max(worst, check_mix<Mix3<12, 12, 10, 128>>());
+    worst = std::max(worst, check_mix<Mix3<16, 4, 19, 128>>());
+    worst = std::max(worst, check_mix<Mix3<10, 12, 10, 128>>());
+    worst = std::max(worst, check_mix<Mix3<12, 10, 9, 128>>());
+    worst = std::max(worst, check_mix<Mix3<16, 8, 8, 128>>());
+    worst = std::max(worst, check_mix<Mix3<10, 10, 10, 128>>());
+    worst = std::max(worst, check_mix<Mix3<16, 12, 5, 128>>());
+    worst = std::max(worst, check_mix<Mix3<16, 10, 5, 128>>());
+    worst = std::max(worst, check_mix<Mix3<8, 8, 12, 64>>());
+    worst = std::max(worst, check_mix<Mix3<16, 8, 5, 64>>());
+    worst = std::max(worst, check_mix<Mix3<16, 6, 6, 64>>());
+    worst = std::max(worst, check_mix<Mix3<12, 9, 5, 64>>());
+    worst = std::max(worst, check_mix<Mix3<8, 8, 8, 64>>());
+    worst = std::max(worst, check_mix<Mix3<8, 6, 10, 64>>());
     printf(worst < 2e-6 ? "OK\n" : "FAIL\n");
     return worst < 2e-6 ? 0 : 1;
 }

@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r8
-timeout -k 10 900 python -m pytest tests/test_gpu_signal.py -x -q -m gpu > gpurun_out/r8/pytest.log 2>&1; tail -15 gpurun_out/r8/pytest.log
+mkdir -p gpurun_out/r9
+timeout -k 10 1100 python -m pytest tests/test_gpu_signal.py tests/test_gpu_wiener.py tests/test_gpu_tracking.py -x -q -m gpu --durations=8 > gpurun_out/r9/pytest.log 2>&1; tail -25 gpurun_out/r9/pytest.log
