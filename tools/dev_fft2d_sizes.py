@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, ".")
 from barc4dip_amd.signal.fft import fft2d_stack  # noqa: E402
 
-for (ny, nx, T) in ((600, 600, 256), (720, 1280, 128), (2160, 2560, 32), (264, 520, 256), (4104, 4104, 8), (1000, 2048, 32)):
+for (ny, nx, T) in ((600, 600, 256), (720, 1280, 128), (2160, 2560, 32), (264, 520, 256), (4104, 4104, 8), (1000, 2048, 32), (1080, 1920, 64), (2048, 2448, 32), (3000, 4096, 8)):
     st = torch.rand((T, ny, nx), device="cuda") * 1000
     out = fft2d_stack(st, return_tensors=True)
     ref = torch.fft.fftshift(torch.fft.fft2(st.double()), dim=(-2, -1))

@@ -8,7 +8,8 @@ sys.path.insert(0, ".")
 from barc4dip_amd import _ffi, synth  # noqa: E402
 from barc4dip_amd.signal import psd_autocorr2d_stack  # noqa: E402
 
-for (ny, nx, T) in ((512, 512, 1024), (1024, 1024, 512), (2048, 2048, 256), (4096, 4096, 64), (228, 228, 2048), (2160, 2560, 64), (4104, 4104, 16)):
+for (ny, nx, T) in ((512, 512, 1024), (1024, 1024, 512), (2048, 2048, 256), (4096, 4096, 64), (228, 228, 2048), (2160, 2560, 64), (4104, 4104, 16),
+                    (1080, 1920, 128), (1200, 1600, 128), (1536, 2048, 64), (2048, 2448, 64), (3000, 4096, 16), (480, 640, 512)):
     st = torch.rand((T, ny, nx), device="cuda") * 1000
     psd_autocorr2d_stack(st, return_tensors=True)
     torch.cuda.synchronize()

@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/r9
-timeout -k 10 1100 python -m pytest tests/test_gpu_signal.py tests/test_gpu_wiener.py tests/test_gpu_tracking.py -x -q -m gpu --durations=8 > gpurun_out/r9/pytest.log 2>&1; tail -25 gpurun_out/r9/pytest.log
+timeout -k 10 600 python tools/dev_sizes.py > gpurun_out/r9/sizes.log 2>&1; cat gpurun_out/r9/sizes.log
+timeout -k 10 600 python tools/dev_fft2d_sizes.py > gpurun_out/r9/fft2d.log 2>&1; cat gpurun_out/r9/fft2d.log
