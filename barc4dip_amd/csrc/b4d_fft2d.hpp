@@ -539,9 +539,15 @@ struct RowOutArgs {
     float* compact;
     int half;            // C2R_OUT: the map is even (R[-y,-x] = R[y,x], autocorrelation): transform rows 0..ny/2 only
                          // and write every row together with its point mirror
+    // C2R_MAG without the map (tracking): partials, counts and the gathered bin are everything the common path reads of the
+    // 4 ny nx bytes -- except the 3 x 3 neighbourhood of the peak, which C2R_ROWS writes afterwards (three row pairs).
+    int nomap;           // C2R_MAG: do not store the map
+    int nblk;            // C2R_ROWS: partials per frame
+    const unsigned* gate;   // C2R_MAG, optional: skip frame f when gate[f * gate_stride] != 0 (pairs that need no full map)
+    int gate_stride;
 };
 
-enum RowOutMode { C2R_OUT = 0, C2R_PEAK = 1, C2R_MAG = 2 };
+enum RowOutMode { C2R_OUT = 0, C2R_PEAK = 1, C2R_MAG = 2, C2R_ROWS = 3 };
 
 // (value, flat index) arg-max with NumPy's first-occurrence rule: larger value wins, ties go to the lower index
 __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
@@ -561,9 +567,39 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
     constexpr int T = G::T, E = E16;
     __shared__ float2 lds_all[SEQ * G::LDS_ELEMS];
     const int seq = threadIdx.x / T, u = threadIdx.x % T;
-    const int pair = MODE == C2R_PEAK ? 0 : blockIdx.x * SEQ + seq;
     const size_t frame = blockIdx.y;
     const int ny = p.ny, ct_w = p.ct_w, nt = (NX / 2) / ct_w;
+    if (MODE == C2R_MAG && p.gate && p.gate[frame * p.gate_stride]) return;
+    int peak_pair = 0;
+    if (MODE == C2R_ROWS) {   // first-occurrence arg-max over the frame's partials -> the row pair that holds the peak
+        float bv = -1.0f;
+        int bi = 0x7fffffff;
+        for (int i = threadIdx.x; i < p.nblk; i += T * SEQ) argmax_merge(bv, bi, p.part_val[frame * p.nblk + i], p.part_idx[frame * p.nblk + i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_down(bv, o, 64);
+            const int oi = __shfl_down(bi, o, 64);
+            argmax_merge(bv, bi, ov, oi);
+        }
+        float* sv = reinterpret_cast<float*>(lds_all);
+        int* si = reinterpret_cast<int*>(lds_all) + 32;
+        if ((threadIdx.x & 63) == 0) {
+            sv[threadIdx.x >> 6] = bv;
+            si[threadIdx.x >> 6] = bi;
+        }
+        __syncthreads();
+        bv = sv[0];
+        bi = si[0];
+        for (int i = 1; i < (T * SEQ + 63) / 64; ++i) argmax_merge(bv, bi, sv[i], si[i]);
+        __syncthreads();
+        const int yr = bi == 0x7fffffff ? 0 : bi / NX;          // row of the shifted map
+        peak_pair = ((yr + ny / 2) & (ny - 1)) >> 1;
+    }
+    const int nblk = gridDim.x, bx = blockIdx.x;
+    // C2R_ROWS: the pairs peak - 1, peak, peak + 1 (cyclic) hold rows y - 1 .. y + 1 of the peak row y, whatever its parity
+    const int pair = MODE == C2R_PEAK   ? 0
+                     : MODE == C2R_ROWS ? (peak_pair + ny / 2 - 1 + min(bx * SEQ + seq, 2)) % (ny / 2)
+                                        : bx * SEQ + seq;
     const bool live = (MODE == C2R_OUT && p.half) ? 2 * pair <= ny / 2 : 2 * pair < ny;
     const int yl = live ? 2 * pair : 0;
     float2* lds = lds_all + seq * G::LDS_ELEMS;
@@ -623,6 +659,15 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
         }
         return;
     }
+    if (MODE == C2R_ROWS) {   // the same values the map would hold, for the rows around the peak only
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int x = u + T * j, c = (x + NX / 2) & (NX - 1);
+            o0[c] = fabsf(v[j].y * p.scale);
+            o1[c] = fabsf(v[j].x * p.scale);
+        }
+        return;
+    }
     // ---- C2R_MAG
     float bv = -1.0f;
     int bi = 0x7fffffff;
@@ -635,8 +680,10 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
         for (int j = 0; j < E; ++j) {
             const int x = u + T * j, c = (x + NX / 2) & (NX - 1);
             const float m0 = fabsf(v[j].y * p.scale), m1 = fabsf(v[j].x * p.scale);
-            o0[c] = m0;
-            o1[c] = m1;
+            if (!p.nomap) {
+                o0[c] = m0;
+                o1[c] = m1;
+            }
             argmax_merge(bv, bi, m0, ra * NX + c);
             argmax_merge(bv, bi, m1, rb * NX + c);
             if (pbx != 0xffffffffu) {
@@ -664,8 +711,8 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 1; i < nw; ++i) argmax_merge(bv, bi, sv[i], si[i]);
-        p.part_val[frame * gridDim.x + blockIdx.x] = bv;
-        p.part_idx[frame * gridDim.x + blockIdx.x] = bi;
+        p.part_val[frame * nblk + bx] = bv;
+        p.part_idx[frame * nblk + bx] = bi;
     }
     if (p.selw && p.pred_bin) {
         // counts of the magnitudes below / inside the expected median bin and the bin's elements themselves: lane counts,
@@ -890,7 +937,15 @@ static int launch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, int mo
     if (nblk) *nblk = grid.x;
     if (batch < 1) return B4D_OK;
     if (mode == C2R_MAG) {
+        // with a.gate (full maps for the few frames that need them) the workgroups of every other frame leave at once; a loop
+        // over row blocks inside the kernel instead of the full grid was tried: the compiler hoists the transform's twiddle
+        // and address set out of it (92 -> 236 VGPRs, half the occupancy of the main pass that shares the instantiation)
         hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_MAG>), grid, block, 0, st, a);
+        B4D_HIP(hipGetLastError());
+        return B4D_OK;
+    }
+    if (mode == C2R_ROWS) {   // three row pairs around each frame's peak (a.nblk partials per frame)
+        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_ROWS>), dim3((3 + SEQ - 1) / SEQ, batch), block, 0, st, a);
         B4D_HIP(hipGetLastError());
         return B4D_OK;
     }

@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS, ColCfg<NY>::WAVES_PER_EU)
 // ------------------------------------------------------------------------------------ tracking epilogue
 struct FinArgs {
     const float* mag;       // (pairs, ny, nx)
+    int partial_map;        // k_track_fin2: only the rows around the peak are valid in `mag` (k_row_c2r C2R_MAG nomap + C2R_ROWS)
     const float* part_val;  // (pairs, nblk)
     const int* part_idx;
     double* out;            // (pairs, 4): dy, dx, peak, snr
@@ -280,13 +281,14 @@ constexpr int SEL_WORDS = sizeof(SelState) / sizeof(unsigned);
 // is where the median of nearly every pair falls.  k_row_c2r counts the elements below / inside that bin and gathers the
 // bin while it writes the map; pairs whose counts put the median elsewhere take the full three-pass select on the map
 // (k_track_fin).  Exactness never depends on the guess.
-static bool g_track_predict = true;     // b4d_set_option("track_predict_bin", 0 / 1): tests run both ways
+static int g_track_predict = 1;     // b4d_set_option("track_predict_bin", 0 / 1 / 2): off, on, on with a deliberately WRONG bin
+                                    // (every pair then takes the gated full-map pass behind the map-free one: tests run all three)
 static unsigned predicted_median_bin(size_t n) {
     if (!g_track_predict) return 0u;
     const float med = (float)(0.6744897501960817 / std::sqrt((double)n));
     unsigned bits;
     memcpy(&bits, &med, sizeof(bits));
-    return 1024u + (bits >> 21);
+    return 1024u + (bits >> 21) + (g_track_predict == 2 ? 3u : 0u);
 }
 
 // grid (ceil(pairs / 64)), block 64: the expectation holds for pair i when the median's rank falls inside the expected bin
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(64) k_track_select(size_t n, SelState* __restr
 }
 
 // grid (pairs), block 1024, dynamic LDS FIN_LDS bytes
-__global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, const SelState* __restrict__ sel) {
+__global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, SelState* __restrict__ sel) {
     constexpr int REP = FIN_REP;
     extern __shared__ unsigned hist[];
     __shared__ unsigned sh[4];
@@ -344,7 +346,13 @@ __global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, const SelState* 
         float a = key2f(ka), b = a;
         if (nl + ne <= n / 2) {  // upper middle value = next larger element: in the gathered bin, else (rare) anywhere above it
             unsigned kb = next_larger_key(cx, cn, ka, hist);
-            if (kb == 0xffffffffu) kb = next_larger_key(mag, n, ka, hist);
+            if (kb == 0xffffffffu) {   // (rare) the upper middle value lies above the gathered bin: that needs the whole map
+                if (p.partial_map) {   // hand the pair to the full-map route (uniform: every lane holds the same kb)
+                    if (threadIdx.x == 0) sel[pair].ok = 0u;
+                    return;
+                }
+                kb = next_larger_key(mag, n, ka, hist);
+            }
             b = key2f(kb);
         }
         med = __fmul_rn(__fadd_rn(a, b), 0.5f);
@@ -362,9 +370,13 @@ static int launch_track_fin2(const FinArgs& fa, SelState* sel, unsigned pred, in
     B4D_HIP(attr_err);
     const size_t n = (size_t)fa.ny * fa.nx;
     hipLaunchKernelGGL(k_track_select, dim3((pairs + 63) / 64), dim3(64), 0, st, n, sel, pred, pairs);
-    hipLaunchKernelGGL(k_track_fin2, dim3(pairs), dim3(1024), FIN_LDS, st, fa, (const SelState*)sel);
+    hipLaunchKernelGGL(k_track_fin2, dim3(pairs), dim3(1024), FIN_LDS, st, fa, sel);
     B4D_HIP(hipGetLastError());
-    FinArgs fb = fa;            // the pairs whose expectation failed (all of them when it is switched off)
+    return B4D_OK;
+}
+// the pairs whose expectation failed (all of them when it is switched off): whole selection on the (full) map
+static int launch_track_fin_rest(const FinArgs& fa, SelState* sel, int pairs, hipStream_t st) {
+    FinArgs fb = fa;
     fb.skip = &sel[0].ok;
     fb.skip_stride = SEL_WORDS;
     return launch_track_fin(fb, pairs, st);
@@ -856,6 +868,7 @@ static int wmr_phase_correlation(b4d_plan* pl, const float* images, int nimg, co
         fa.subpixel = subpixel;
         fa.eps = eps;
         if ((rc = launch_track_fin2(fa, msel, pred, np, st))) return rc;
+        if ((rc = launch_track_fin_rest(fa, msel, np, st))) return rc;
     }
     return B4D_OK;
 }
@@ -986,7 +999,7 @@ int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* 
 int b4d_set_option(const char* name, int value) {
     if (!name) return fail(B4D_EINVAL, "null option name");
     if (!strcmp(name, "track_predict_bin")) {
-        g_track_predict = value != 0;
+        g_track_predict = value;
         return B4D_OK;
     }
     return fail(B4D_EINVAL, std::string("unknown option: ") + name);
@@ -1100,8 +1113,18 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         ra.pred_bin = pred;
         ra.compact = medws;
         B4D_HIP(hipMemsetAsync(msel, 0, sizeof(SelState) * (size_t)pc, st));   // counts, cursors, verdicts
+        // With an expected median bin the common path never reads the map itself: partials, counts and the gathered bin come
+        // out of the row pass, the 3 x 3 Taylor neighbourhood from three row pairs recomputed around the peak (C2R_ROWS).  The
+        // 4 ny nx bytes per pair are written only for the pairs the expectation fails on (gated second pass below).
+        const bool nomap = pred != 0u;
+        ra.nomap = nomap ? 1 : 0;
         int nblk = 0;
         if ((rc = dispatch_c2r(pl, ra, np, st, C2R_MAG, nullptr, &nblk))) return rc;
+        if (nomap) {
+            RowOutArgs rr = ra;
+            rr.nblk = nblk;
+            if ((rc = dispatch_c2r(pl, rr, np, st, C2R_ROWS))) return rc;
+        }
         FinArgs fa{};
         fa.mag = mag;
         fa.compact = medws;
@@ -1114,7 +1137,17 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         fa.nblk = nblk;
         fa.subpixel = subpixel;
         fa.eps = eps;
+        fa.partial_map = nomap ? 1 : 0;
         if ((rc = launch_track_fin2(fa, msel, pred, np, st))) return rc;
+        if (nomap) {   // full maps for the pairs left over (verdict word of the select state != 0: nothing to do)
+            RowOutArgs rf = ra;
+            rf.nomap = 0;
+            rf.selw = nullptr;
+            rf.gate = &msel[0].ok;
+            rf.gate_stride = SEL_WORDS;
+            if ((rc = dispatch_c2r(pl, rf, np, st, C2R_MAG))) return rc;
+        }
+        if ((rc = launch_track_fin_rest(fa, msel, np, st))) return rc;
         B4D_HIP(hipGetLastError());
     }
     return B4D_OK;

@@ -346,10 +346,12 @@ def test_cfg3_size(gs):
 
 
 def test_median_bin_prediction_is_only_a_route(gs):
-    """b4d_phase_correlation gathers the EXPECTED median bin of every |corr| map while it writes the map (whitened maps:
-    median ~ 0.6745 / sqrt(N)) and falls back to a second read of the map per pair when the histogram disagrees.  Both
-    routes must give bit-identical rows -- with the expectation switched off every pair takes the fallback -- and an
-    un-whitened-looking input (a constant template region: degenerate map) must survive a wrong expectation."""
+    """b4d_phase_correlation gathers the EXPECTED median bin of every |corr| map in the pass that produces it (whitened maps:
+    median ~ 0.6745 / sqrt(N)) and, with an expectation, does not store the map at all: three row pairs around the peak are
+    recomputed for the Taylor step, and only pairs whose histogram disagrees get their full map from a gated second pass.
+    All routes must give bit-identical rows -- expectation off (every pair on the full map written by the first pass),
+    expectation on, expectation deliberately wrong (every pair through the gated pass) -- and an un-whitened-looking input
+    (a constant template region: degenerate map) must survive a wrong expectation."""
     from barc4dip_amd import _ffi
 
     stack, sh = synth.shifted_stack(4, 512, seed=77, max_shift=12)
@@ -363,13 +365,14 @@ def test_median_bin_prediction_is_only_a_route(gs):
     lib = _ffi.lib()
     out = {}
     try:
-        for mode in (1, 0):
+        for mode in (1, 0, 2):   # 2: a deliberately wrong bin -- the map-free pass, then the gated full-map pass for every pair
             assert lib.b4d_set_option(b"track_predict_bin", mode) == 0
             out[mode] = (gs.phase_correlation_batch(stack, stack, tpl_frame, tpl_roi, pair_img, pair_tpl, return_peak_ij=True),
                          gs.phase_correlation_batch(flat, flat, tpl_frame, tpl_roi, pair_img, pair_tpl, return_peak_ij=True))
     finally:
         lib.b4d_set_option(b"track_predict_bin", 1)
-    for a, b in zip(out[1], out[0]):
-        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
+    for m in (1, 2):
+        for a, b in zip(out[m], out[0]):
+            assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
     assert lib.b4d_set_option(b"no_such_option", 1) != 0
     assert np.all(np.rint(out[1][0][0][:8, 0]).reshape(4, 2) == sh[:, 0:1])

@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/r9
-timeout -k 10 600 python tools/dev_sizes.py > gpurun_out/r9/sizes.log 2>&1; cat gpurun_out/r9/sizes.log
-timeout -k 10 600 python tools/dev_fft2d_sizes.py > gpurun_out/r9/fft2d.log 2>&1; cat gpurun_out/r9/fft2d.log
+mkdir -p gpurun_out/r10
+timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py tests/test_gpu_metrics.py -x -q -m gpu > gpurun_out/r10/pytest.log 2>&1; tail -5 gpurun_out/r10/pytest.log
