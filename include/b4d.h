@@ -42,9 +42,12 @@ typedef struct b4d_plan b4d_plan;
 /* Library / device ------------------------------------------------------------------- */
 const char* b4d_version(void);
 const char* b4d_last_error(void);
-/* Process-wide switches that never change results, only the route taken (tests run both routes):
- *   "track_predict_bin"  0 / 1 (default 1): b4d_phase_correlation counts and gathers the expected median bin of every correlation
- *                        map while it writes the map; 0 = always run the full select on the map (the fallback of a wrong expectation). */
+/* Process-wide switches that never change results, only the route taken (tests run every route):
+ *   "track_predict_bin"  0 / 1 / 2 (default 1): 1 = b4d_phase_correlation counts and gathers the EXPECTED median bin of every
+ *                        correlation map in the pass that produces it and (power-of-two sizes) does not store the map: the rows
+ *                        around the peak are recomputed for the sub-pixel step, pairs whose expectation fails get their full map
+ *                        from a second, gated pass; 0 = no expectation: full maps, full select; 2 = a deliberately wrong
+ *                        expectation (test hook: every pair takes the gated pass). */
 int b4d_set_option(const char* name, int value);
 /* 1 if (ny, nx) has a plan: powers of two in [64, 4096] (radix FFT kernels); any sides <= 512 (DFT-matrix products);
  * sides <= 8192 that split as 2^k * A * B with A + B <= 128 (fused in-LDS mixed radix) or any other side <= 4096
