@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/r12
-timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py -x -q -m gpu -k "power_of_two_sizes" > gpurun_out/r12/pytest.log 2>&1; tail -30 gpurun_out/r12/pytest.log
+cp barc4dip_amd/csrc/libb4d_ns.so barc4dip_amd/csrc/libb4d.so
+bash tools/prof_stats.sh r12/prof_cfg3_nosel tools/bench_configs.py 3 | awk -F'","' '{print substr($1,1,70), $2, $3, $4, $5}' | head -8
