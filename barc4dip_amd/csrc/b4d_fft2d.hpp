@@ -211,6 +211,34 @@ struct __attribute__((packed, aligned(4))) float4_u {
     float x, y, z, w;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // plain vector values for accesses through address-space pointers
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define B4D_GLOBAL __attribute__((address_space(1)))
+// Address = uniform base + 32-bit BYTE offset of the lane: the form global_load/store take with the base in SGPRs and ONE offset
+// VGPR.  With element indices the compiler cannot fold the scaling into a 32-bit offset (it could wrap) and builds 64-bit
+// per-lane addresses: two VGPRs each, kept live across the transforms at the 128-register cap of the 1024-lane kernels.
+template <class V>
+__device__ __forceinline__ V B4D_GLOBAL* at_bytes(void* base, unsigned boff) {
+    return (V B4D_GLOBAL*)((char B4D_GLOBAL*)base + boff);
+}
+template <class V>
+__device__ __forceinline__ const V B4D_GLOBAL* at_bytes(const void* base, unsigned boff) {
+    return (const V B4D_GLOBAL*)((const char B4D_GLOBAL*)base + boff);
+}
+// a uniform pointer pinned in an SGPR pair and opaque to reassociation: `sgpr_base(p + const) + lane offset` stays
+// "scalar base + 32-bit lane offset" instead of being folded into a 64-bit per-lane address plus constants
+template <class V>
+__device__ __forceinline__ V* sgpr_base(V* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+template <int NC>
+__device__ __forceinline__ void store_cols(f32x2 B4D_GLOBAL* rowp, const float2 (&c)[NC]) {
+#pragma unroll
+    for (int h = 0; h < NC / 2; ++h)
+        *(f32x4 B4D_GLOBAL*)(rowp + 2 * h) = f32x4{c[2 * h].x, c[2 * h].y, c[2 * h + 1].x, c[2 * h + 1].y};
+}
 template <int NC>
 __device__ __forceinline__ void store_cols(float2* __restrict__ rowp, const float2 (&c)[NC]) {
 #pragma unroll
@@ -269,7 +297,7 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
                 v[2 * h][j] = make_float2(q.x, q.y);
                 v[2 * h + 1][j] = make_float2(q.z, q.w);
             } else {
-                const float4 q = *reinterpret_cast<const float4*>(tile + (size_t)(T * j * CT) + toff + 2 * h);
+                const f32x4 q = *at_bytes<f32x4>(sgpr_base(tile + (size_t)(T * j * CT) + 2 * h), toff * 8u);
                 v[2 * h][j] = make_float2(q.x, q.y);
                 v[2 * h + 1][j] = make_float2(q.z, q.w);
             }
@@ -351,7 +379,7 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
                     *reinterpret_cast<float4*>(&psd[rd + nx / 2 + kx0]) =
                         make_float4(pw[0] * s, pw[1] * s, pw[2 % NC] * s, pw[3 % NC] * s);
                 else
-                    *reinterpret_cast<float2*>(&psd[rd + nx / 2 + kx0]) = make_float2(pw[0] * s, pw[1] * s);
+                    *at_bytes<f32x2>(psd, (rd + nx / 2 + kx0) * 4u) = f32x2{pw[0] * s, pw[1] * s};
                 // Hermitian mirror: columns nx/2 - kx0 - k, descending -> one reversed (4-byte aligned) vector store
                 if (NC == 4 && kx0 >= 1) {
                     float4_u m;
@@ -374,9 +402,11 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
                         psd[rm + nx / 2 - kx0 - 1] = pw[1] * s;
                     if (cpm == 0 && kx0 >= 1) psd[rm + nx / 2 - kx0] = pw[0] * s;
 #else
-#pragma unroll
-                    for (int k = 0; k < NC; ++k)
-                        if (kx0 + k >= 1) psd[rm + nx / 2 - kx0 - k] = pw[k] * s;
+                    // columns nx/2 - kx0 - 1, nx/2 - kx0 (column 0 has no mirror).  Two dword stores: ONE 8-byte store on the 4-byte
+                    // boundary (the mirror of an aligned pair starts one float off) measured +6 % on the kernel
+                    const unsigned mo = (rm + nx / 2 - kx0 - 1) * 4u;
+                    *at_bytes<float>(psd, mo) = pw[1] * s;
+                    if (kx0 >= 1) *at_bytes<float>(psd, mo + 4u) = pw[0] * s;
 #endif
                 }
             }
@@ -388,13 +418,16 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
     B4D_STAMP(3);
     B4D_DRAIN();
     B4D_STAMP(4);
-    if (kx0 == 0 && u == 0 && (p.flags & B4D_REMOVE_MEAN)) w[0][0].y = 0.f;  // DC bin: ky = 0 <-> u = 0, j = 0
-    // Launder the offset: otherwise the compiler keeps the 64-bit load addresses alive across the whole kernel.
+    if (kx0 == 0 && uu == 0 && (p.flags & B4D_REMOVE_MEAN)) w[0][0].y = 0.f;  // DC bin: ky = 0 <-> u = 0, j = 0
+    // The lane position is derived AGAIN from the (laundered) thread index: otherwise the compiler keeps the load addresses and
+    // the ~40 twiddle / LDS byte offsets of the forward pass alive, or u, cp and the tile offset in three registers where one
+    // does -- at the 128-register cap one spilled dword reloaded here would be a scratch load, i.e. a vmcnt(0) that drains
+    // every PSD store before the inverse transform may start
     const float2* tw2 = p.tw_inv;
-    unsigned toff2 = toff;
-    asm volatile("" : "+v"(toff2));
-    int u2 = u, cp2 = cp;   // likewise the ~40 twiddle / LDS byte offsets derived from the lane position
-    asm volatile("" : "+v"(u2), "+v"(cp2));
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int cp2 = tid2 % CPT, u2 = tid2 / CPT;
+    const unsigned toff2 = (unsigned)u2 * CT + NC * (cp2 + CPT * (slot % SPLIT));
     __syncthreads();
     Fft3<G, 1>::template run_sets<NC / 2, Cfg::SERIAL, true, Cfg::SB>(w, u2, cp2, lds, tw2);
     B4D_STAMP(5);
@@ -407,12 +440,12 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
 #pragma unroll
         for (int h = b; h < b + Cfg::SB; ++h)
 #pragma unroll
-            for (int j = 0; j < E; ++j) lds[(h - b) * SETE + (u + T * j) * CPT + cp] = make_float2(w[h][j].y, w[h][j].x);
+            for (int j = 0; j < E; ++j) lds[(h - b) * SETE + (u2 + T * j) * CPT + cp2] = make_float2(w[h][j].y, w[h][j].x);
         __syncthreads();
 #pragma unroll
         for (int h = b; h < b + Cfg::SB; ++h)
 #pragma unroll
-            for (int j = 0; j < E; ++j) vr[h][j] = lds[(h - b) * SETE + ((NY - (u + T * j)) & (NY - 1)) * CPT + cp];
+            for (int j = 0; j < E; ++j) vr[h][j] = lds[(h - b) * SETE + ((NY - (u2 + T * j)) & (NY - 1)) * CPT + cp2];
     }
 #pragma unroll
     for (int j = 0; j < E; ++j) {
@@ -423,7 +456,7 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
             c[2 * h] = make_float2(0.5f * (z.x + zr.x), 0.5f * (z.y - zr.y));
             c[2 * h + 1] = make_float2(0.5f * (z.y + zr.y), 0.5f * (zr.x - z.x));
         }
-        if (!p.half_rows || u + T * j <= NY / 2 + 1) store_cols<NC>(tile + (size_t)(T * j * CT) + toff2, c);
+        if (!p.half_rows || u2 + T * j <= NY / 2 + 1) store_cols<NC>(at_bytes<f32x2>(sgpr_base(tile + (size_t)(T * j * CT)), toff2 * 8u), c);
     }
     B4D_STAMP(6);
     B4D_DRAIN();

@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r12
-cp barc4dip_amd/csrc/libb4d_ns.so barc4dip_amd/csrc/libb4d.so
-bash tools/prof_stats.sh r12/prof_cfg3_nosel tools/bench_configs.py 3 | awk -F'","' '{print substr($1,1,70), $2, $3, $4, $5}' | head -8
+mkdir -p gpurun_out/r13
+timeout -k 10 300 python tools/dev_ab.py barc4dip_amd/csrc/libb4d_base.so barc4dip_amd/csrc/libb4d.so > gpurun_out/r13/ab.log 2>&1; cat gpurun_out/r13/ab.log
+timeout -k 10 900 python -m pytest tests/test_gpu_signal.py tests/test_gpu_tracking.py -x -q -m gpu > gpurun_out/r13/pytest.log 2>&1; tail -3 gpurun_out/r13/pytest.log
