@@ -73,6 +73,7 @@ SIGNATURES = {
     "b4d_wiener_create": (_i, [_i, _i, _vp, _i, _i, _f, C.POINTER(_vp)]),
     "b4d_wiener_apply": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "b4d_wiener_destroy": (_i, [_vp]),
+    "b4d_uw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_ulonglong, _i, _i, C.c_float, C.c_float, _i, _i, _vp, _vp]),
 }
 
 

@@ -7,12 +7,17 @@ the padded size, clip, rescale, crop: b4d_wiener_*).  The reference delegates th
 definition (Laplacian regulariser, `balance`) and parity is UNPINNED.  ``method="rl"`` runs
 Richardson-Lucy as published for ``skimage.restoration.richardson_lucy`` (``b4d_richardson_lucy``: two LDS-tiled
 direct convolutions per iteration, same padding / normalisation / crop; parity likewise unpinned).  ``method="uw"``
-(scikit-image's stochastic unsupervised Wiener-Hunt sampler) is not built.
+runs scikit-image's unsupervised Wiener-Hunt Gibbs sampler as published (``b4d_uw_step``: one fused pass over the
+half-plane spectrum per sweep; transforms through the library's own fft2d / ifft2d; the two Gamma draws per sweep on the
+host).  It is stochastic by construction -- the reference passes no ``rng``, two of its own runs differ -- so the extra
+keyword ``rng`` exists here: ``None`` draws the normals on the device (Philox), an int / ``numpy.random.Generator`` replays
+the library's host stream (two normal fields, two Gamma variates per sweep), which is what the tests compare.
 """
 from __future__ import annotations
 
 import ctypes as C
 import logging
+import os
 from typing import Literal, Sequence
 
 import numpy as np
@@ -82,6 +87,93 @@ class _WienerPlan:
             pass
 
 
+def _uw_one_frame(frame, psf: np.ndarray, clip: bool, reg, user_params, rng):
+    """method='uw' for one device frame (H, W) float32 -> restored device frame (filters.py:252-289 around
+    skimage.restoration.unsupervised_wiener, published algorithm; see csrc/b4d_uw.hip for the sweep)."""
+    import torch
+
+    from ..signal import fft as sfft
+
+    params = {"threshold": 1e-4, "max_num_iter": 200, "min_num_iter": 30, "burnin": 15, "callback": None}
+    params.update(user_params or {})
+    py, px = int(psf.shape[0] // 2), int(psf.shape[1] // 2)
+    padded = torch.nn.functional.pad(frame[None, None], (px, px, py, py), mode="reflect")[0, 0]
+    mag = padded.abs()
+    finite = mag[~torch.isnan(mag)]                       # np.nanmax: NaNs are skipped, an all-NaN frame has no scale
+    scale = float(finite.max()) if finite.numel() else float("nan")
+    if not np.isfinite(scale) or scale == 0.0:
+        return torch.zeros_like(frame)
+    work = (padded / scale).to(torch.float32).contiguous()
+    ny, nx = (int(v) for v in work.shape)
+    nxh, npix = nx // 2 + 1, ny * nx
+
+    def half_spectrum(img2d):                             # rfft2 layout out of the library's shifted full spectrum
+        F = sfft.fft2d_stack(img2d[None], return_tensors=True)[0]
+        return torch.roll(F, shifts=(-(ny // 2), -(nx // 2)), dims=(0, 1))[:, :nxh].contiguous()
+
+    def ir2tf(kernel):                                    # kernel centred on the origin of an image-sized array
+        big = np.zeros((ny, nx), dtype=np.float32)
+        big[:kernel.shape[0], :kernel.shape[1]] = kernel
+        for ax, k in enumerate(kernel.shape):
+            big = np.roll(big, -int(np.floor(k / 2)), axis=ax)
+        return half_spectrum(torch.from_numpy(big).to(work.device))
+
+    if reg is None:
+        lap = np.zeros((3, 3), dtype=np.float32)
+        lap[1, 1] = 4.0
+        lap[0, 1] = lap[2, 1] = lap[1, 0] = lap[1, 2] = -1.0
+        L = ir2tf(lap)
+    elif np.iscomplexobj(reg):
+        L = torch.from_numpy(np.ascontiguousarray(reg, dtype=np.complex64)).to(work.device)
+        if tuple(L.shape) != (ny, nxh):
+            raise ValueError(f"reg: a transfer function must have the half-plane shape {(ny, nxh)} of the padded frame")
+    else:
+        L = ir2tf(np.asarray(reg, dtype=np.float32))
+    H = ir2tf(np.asarray(psf, dtype=np.float32))
+    areg2 = (L.real * L.real + L.imag * L.imag).contiguous()
+    Y = (half_spectrum(work) / float(np.sqrt(npix))).contiguous()          # unitary transform
+    post = torch.zeros_like(Y)
+    xs = torch.empty_like(Y) if params["callback"] else None
+    sums = torch.zeros(4, dtype=torch.float64, device=work.device)
+    host_normals = rng is not None
+    gen = np.random.default_rng(rng)
+    seed = 0 if host_normals else int.from_bytes(os.urandom(8), "little")   # like the reference: a fresh stream per call
+    lib = _ffi.lib()
+    gn, gx = [1.0], [1.0]
+    burn, delta, it = int(params["burnin"]), float("nan"), 0
+    for it in range(int(params["max_num_iter"])):
+        r1 = r2 = None
+        if host_normals:                                   # the library's order of draws: two normal fields, then two Gamma variates
+            r1 = torch.from_numpy(gen.standard_normal((ny, nxh)).astype(np.float32)).to(work.device)
+            r2 = torch.from_numpy(gen.standard_normal((ny, nxh)).astype(np.float32)).to(work.device)
+        _ffi.check(lib.b4d_uw_step(D.ptr(Y), D.ptr(H), D.ptr(areg2), D.ptr(xs) if xs is not None else None, D.ptr(post),
+                                   D.ptr(r1) if r1 is not None else None, D.ptr(r2) if r2 is not None else None, seed, it, burn,
+                                   float(gn[-1]), float(gx[-1]), ny, nxh, D.ptr(sums), _ffi.stream_ptr()))
+        q1, q2, d1, d2 = (float(v) for v in sums.cpu().numpy())
+        if params["callback"]:
+            params["callback"](xs.cpu().numpy())
+        gn.append(gen.gamma(npix / 2, 2 / q1))
+        gx.append(gen.gamma((npix - 1) / 2, 2 / q2))
+        if it > burn + 1:
+            delta = d1 / d2 / (it - burn)
+        if it > params["min_num_iter"] and delta < params["threshold"]:
+            break
+    post = post / float(it - burn)
+    # full Hermitian spectrum -> the library's ifft2d (fftshift-ed input); Re(ifft2) of it is irfft2 of the half plane
+    full = torch.empty((ny, nx), dtype=post.dtype, device=post.device)
+    full[:, :nxh] = post
+    if nx - nxh > 0:
+        ky = (-torch.arange(ny, device=post.device)) % ny
+        kx = nx - torch.arange(nxh, nx, device=post.device)
+        full[:, nxh:] = torch.conj(post[ky][:, kx])
+    full = torch.roll(full, shifts=(ny // 2, nx // 2), dims=(0, 1)).contiguous()
+    out = sfft.ifft2d(full, return_tensors=True).real * float(np.sqrt(npix))   # unitary inverse
+    if clip:
+        out = out.clamp(-1.0, 1.0)
+    out = (out.to(torch.float32) * scale)[py:ny - py, px:nx - px]
+    return out.contiguous()
+
+
 _wiener_plans: dict = {}
 
 
@@ -104,7 +196,7 @@ def deconvolve_psf(images: np.ndarray, *, sigma: float | Sequence[float], method
                    pad_mode: Literal["reflect"] = "reflect", balance: float | None = None, num_iter: int = 50,
                    filter_epsilon: float | None = None, reg: float | None = None, user_params: dict | None = None,
                    is_real: bool = True, parallel: bool = True, n_jobs: int | None = None, verbose: bool = False,
-                   return_tensors: bool = False) -> np.ndarray:
+                   return_tensors: bool = False, rng=None) -> np.ndarray:
     """Deconvolve a 2-D image or (T, H, W) stack with a Gaussian PSF of std `sigma` (pixels).  Returns float32 of the
     input shape.  `parallel` / `n_jobs` are accepted for signature compatibility (frames are batched on the device)."""
     if not isinstance(images, np.ndarray) and not D.is_tensor(images):
@@ -117,13 +209,18 @@ def deconvolve_psf(images: np.ndarray, *, sigma: float | Sequence[float], method
         raise ValueError(f"Unsupported method: {method!r}. Use 'wiener', 'rl', or 'uw'.")
     if pad_mode != "reflect":
         raise ValueError("Only pad_mode='reflect' is supported (by design).")
-    if method == "uw":
-        raise NotImplementedError("method='uw' (scikit-image's stochastic unsupervised Wiener-Hunt sampler) is not built on the GPU path.")
+    if method == "uw" and not is_real:
+        raise NotImplementedError("method='uw' with is_real=False (full-plane sampler, complex result) is not built; the default is_real=True is.")
     if balance is None:
         balance = 0.01
     stack = images if images.ndim == 3 else images[None]
     dev, _, _ = D.to_device_f32(stack, ndim=(3,))
-    if method == "rl":
+    if method == "uw":
+        import torch
+
+        gen = np.random.default_rng(rng) if rng is not None else None     # ONE stream over the frames, in frame order
+        out = torch.stack([_uw_one_frame(dev[t], psf, bool(clip), reg, user_params, gen) for t in range(int(dev.shape[0]))])
+    elif method == "rl":
         if num_iter < 1:
             raise ValueError("num_iter must be >= 1 for method='rl'.")
         import torch

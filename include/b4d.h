@@ -221,6 +221,19 @@ int b4d_wiener_destroy(b4d_wiener* plan);
 int b4d_richardson_lucy(const float* frames, int batch, int h, int w, const float* psf, int ky, int kx, int num_iter,
                         float filter_epsilon, int clip, float* out, void* stream);
 
+/* preprocessing/filters.py:278-286 method="uw": ONE Gibbs sweep of skimage.restoration.unsupervised_wiener (published
+ * algorithm, parity unpinned and stochastic: the reference passes no rng) over the unitary half-plane spectrum.  All pointers
+ * DEVICE.  y, tf, x_sample (optional), postmean: (ny, nxh) complex64 (rfft2 layout, nxh = nx/2 + 1); areg2: (ny, nxh) float32
+ * = |Laplacian transfer function|^2; r1 / r2: (ny, nxh) float32 standard normals, or both null: generated on the device
+ * (Philox-4x32-10, key `seed`, counter = element and sweep).  Does
+ *   x = gn conj(tf) / (gn |tf|^2 + gx areg2) * y + sqrt(0.5 / (..)) (r1 + i r2);  postmean += x for sweep > burnin
+ * and leaves in sums4 (4 doubles): ||y - x tf||^2, ||x L||^2 (half-plane weights as the library's image_quad_norm),
+ * sum |postmean/(sweep-burnin) - previous/(sweep-burnin-1)| and sum |postmean| (0 before they are defined).  The Gamma
+ * draws of the two precisions and the loop belong to the caller.  Asynchronous on `stream`.                       */
+int b4d_uw_step(const void* y, const void* tf, const float* areg2, void* x_sample, void* postmean, const float* r1,
+                const float* r2, unsigned long long seed, int sweep, int burnin, float gn, float gx, int ny, int nxh,
+                double* sums4, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,8 +119,77 @@ def richardson_lucy(image, psf, num_iter=50, clip=True, filter_epsilon=None):
     return est.astype(np.float32, copy=False)
 
 
-def deconv_one_frame(frame, psf, balance=0.01, clip=True, method="wiener", num_iter=50, filter_epsilon=None):
-    """preprocessing/filters.py:233-289 (method='wiener' | 'rl')."""
+def image_quad_norm(x):
+    """Published skimage.restoration.uft.image_quad_norm: squared l2 norm of a (possibly half-plane) spectrum.  The
+    Hermitian case is recognised by a NON-SQUARE array and counts every column twice except column 0 (the Nyquist column
+    is counted twice as well: the library's own convention, kept)."""
+    a2 = np.abs(x) ** 2
+    if x.shape[-1] != x.shape[-2]:
+        return 2.0 * np.sum(np.sum(a2, axis=-1), axis=-1) - np.sum(a2[..., 0], axis=-1)
+    return np.sum(np.sum(a2, axis=-1), axis=-1)
+
+
+def unsupervised_wiener(image, psf, reg=None, user_params=None, is_real=True, clip=True, *, rng=None, normals=None):
+    """Unsupervised Wiener-Hunt deconvolution as published for ``skimage.restoration.unsupervised_wiener`` (Orieux,
+    Giovannelli, Rodet, JOSA A 27(7), 2010, Eqs. 27-31, 44; scikit-image API docs) -- PARITY UNPINNED (module header), and
+    stochastic by construction: the reference calls it without ``rng`` (preprocessing/filters.py:278-286), so two runs of
+    the reference itself differ.  Gibbs sampler in the unitary half-plane Fourier domain:
+
+        precision = gn |H|^2 + gx |L|^2;  x = gn conj(H) / precision * Y + sqrt(0.5 / precision) (r1 + i r2)
+        gn ~ Gamma(N / 2, 2 / ||Y - x H||^2),  gx ~ Gamma((N - 1) / 2, 2 / ||x L||^2)
+        posterior mean = average of x after ``burnin``; stop when the relative change of the running mean < threshold.
+
+    ``normals`` (test hook, not in the library): a callable ``normals(iteration, shape) -> (r1, r2)`` replacing the two
+    standard-normal draws, so that another implementation can be fed the very same numbers."""
+    params = {"threshold": 1e-4, "max_num_iter": 200, "min_num_iter": 30, "burnin": 15, "callback": None}
+    params.update(user_params or {})
+    if not is_real:
+        raise ValueError("oracle restates is_real=True only")
+    img = np.asarray(image)
+    ft = np.float32 if img.dtype == np.float32 else np.float64
+    img = img.astype(ft, copy=False)
+    L = laplacian_tf(img.shape, ft) if reg is None else (reg if np.iscomplexobj(reg) else ir2tf(np.asarray(reg, dtype=ft), img.shape, ft))
+    H = ir2tf(np.asarray(psf, dtype=ft), img.shape, ft)
+    ct = np.complex64 if ft == np.float32 else np.complex128
+    L, H = L.astype(ct, copy=False), H.astype(ct, copy=False)
+    areg2, atf2 = np.abs(L) ** 2, np.abs(H) ** 2
+    Y = (np.fft.rfft2(img) / np.sqrt(img.size)).astype(ct, copy=False)       # unitary transform
+    post = np.zeros(H.shape, dtype=ct)
+    prev = np.zeros(H.shape, dtype=ct)
+    delta = np.nan
+    gn, gx = [1.0], [1.0]
+    rng = np.random.default_rng(rng)
+    burn = int(params["burnin"])
+    it = 0
+    for it in range(int(params["max_num_iter"])):
+        precision = (ft(gn[-1]) * atf2 + ft(gx[-1]) * areg2).astype(ft, copy=False)
+        if normals is None:
+            r1 = rng.standard_normal(Y.shape).astype(ft, copy=False)
+            r2 = rng.standard_normal(Y.shape).astype(ft, copy=False)
+        else:
+            r1, r2 = normals(it, Y.shape)
+        x = (ft(gn[-1]) * np.conj(H) / precision) * Y + np.sqrt(ft(0.5) / precision) * (r1 + 1j * r2)
+        x = x.astype(ct, copy=False)
+        if params["callback"]:
+            params["callback"](x)
+        gn.append(rng.gamma(img.size / 2, 2 / image_quad_norm(Y - x * H)))
+        gx.append(rng.gamma((img.size - 1) / 2, 2 / image_quad_norm(x * L)))
+        if it > burn:
+            post = prev + x
+        if it > burn + 1:
+            delta = np.sum(np.abs(post / (it - burn) - prev / (it - burn - 1))) / np.sum(np.abs(post)) / (it - burn)
+        prev = post
+        if it > params["min_num_iter"] and delta < params["threshold"]:
+            break
+    post = post / (it - burn)
+    out = (np.fft.irfft2(post, s=img.shape) * np.sqrt(img.size)).astype(ft, copy=False)    # unitary inverse
+    if clip:
+        out = np.clip(out, -1.0, 1.0)
+    return out, {"noise": gn, "prior": gx}
+
+
+def deconv_one_frame(frame, psf, balance=0.01, clip=True, method="wiener", num_iter=50, filter_epsilon=None, **uw):
+    """preprocessing/filters.py:233-289 (method='wiener' | 'rl' | 'uw'; **uw: reg, user_params, is_real, rng, normals)."""
     if frame.ndim != 2:
         raise ValueError("Internal error: frame must be 2D.")
     py, px = int(psf.shape[0] // 2), int(psf.shape[1] // 2)
@@ -133,27 +202,29 @@ def deconv_one_frame(frame, psf, balance=0.01, clip=True, method="wiener", num_i
         if num_iter < 1:
             raise ValueError("num_iter must be >= 1 for method='rl'.")
         restored = richardson_lucy(work, psf, num_iter=int(num_iter), clip=bool(clip), filter_epsilon=filter_epsilon)
+    elif method == "uw":
+        restored, _ = unsupervised_wiener(work, psf, clip=bool(clip), **uw)
     else:
         restored = wiener(work, psf, float(balance), clip=bool(clip))
     return (restored.astype(np.float32, copy=False) * scale)[py:-py, px:-px]
 
 
 def deconvolve_psf(images, *, sigma, method="wiener", clip=True, pad_mode="reflect", balance=None, num_iter=50,
-                   filter_epsilon=None):
-    """preprocessing/filters.py:17-191 (method='wiener' | 'rl', serial)."""
+                   filter_epsilon=None, **uw):
+    """preprocessing/filters.py:17-191 (serial; **uw reaches unsupervised_wiener for method='uw')."""
     if not isinstance(images, np.ndarray):
         raise TypeError("deconvolve_psf expects a numpy.ndarray")
     if images.ndim not in (2, 3):
         raise ValueError(f"images must be 2D (H, W) or 3D (T, H, W); got ndim={images.ndim}")
     sy, sx = parse_sigma(sigma)
     psf = gaussian_psf(sy, sx, min_size=5)
-    if method not in ("wiener", "rl"):
-        raise ValueError(f"oracle restates method='wiener' and 'rl' only (got {method!r}).")
+    if method not in ("wiener", "rl", "uw"):
+        raise ValueError(f"Unsupported method: {method!r}. Use 'wiener', 'rl', or 'uw'.")
     if pad_mode != "reflect":
         raise ValueError("Only pad_mode='reflect' is supported (by design).")
     if balance is None:
         balance = 0.01
-    kw = dict(method=method, num_iter=num_iter, filter_epsilon=filter_epsilon)
+    kw = dict(method=method, num_iter=num_iter, filter_epsilon=filter_epsilon, **(uw if method == "uw" else {}))
     img = images.astype(np.float32, copy=False)
     if img.ndim == 2:
         return deconv_one_frame(img, psf, balance, clip, **kw).astype(np.float32, copy=False)

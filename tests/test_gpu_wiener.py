@@ -51,6 +51,126 @@ def test_wiener_detector_format(pp):
         assert np.array_equal(out[i], pp.deconvolve_psf(st[i], sigma=1.5))
 
 
+def _blurred_scene(n, m, seed, noise):
+    from scipy.signal import convolve2d
+    from oracle import wiener_np as W
+
+    rng = np.random.default_rng(seed)
+    truth = np.zeros((n, m), np.float32)
+    truth[n // 5:n // 2, m // 4:3 * m // 4] = 1.0
+    truth[3 * n // 5:4 * n // 5, m // 10:m // 3] = 0.5
+    psf = W.gaussian_psf(1.5, 1.5)
+    blur = convolve2d(np.pad(truth, 4, mode="reflect"), psf, mode="same")[4:-4, 4:-4]
+    return truth, (blur + rng.normal(size=blur.shape) * noise).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(60, 52), (120, 248), (256, 256)])   # padded 68 x 60 / 128 x 256 / 264 x 264: three transform routes
+def test_unsupervised_wiener_replays_the_library_stream(pp, shape):
+    """method='uw' (filters.py:278-286 -> skimage.restoration.unsupervised_wiener, published algorithm, parity unpinned).
+    With `rng` given the device sampler consumes the host stream in the library's order (two normal fields, two Gamma
+    variates per sweep), so it must walk the SAME chain as the oracle: posterior mean within 2e-5 of the range, the same
+    number of sweeps, the precision chains within 1e-4."""
+    from oracle import wiener_np as W
+
+    _, img = _blurred_scene(*shape, seed=3, noise=0.02)
+    chains = {}
+
+    def spy(key):
+        def cb(x):
+            chains.setdefault(key, []).append(np.array(x[0, :3]))
+        return cb
+    ref = W.deconvolve_psf(img, sigma=1.5, method="uw", rng=np.random.default_rng(11), user_params={"callback": spy("ref")})
+    got = pp.deconvolve_psf(img, sigma=1.5, method="uw", rng=np.random.default_rng(11), user_params={"callback": spy("got")})
+    assert got.shape == img.shape and got.dtype == np.float32
+    assert len(chains["ref"]) == len(chains["got"]) > 30
+    assert np.allclose(np.array(chains["got"]), np.array(chains["ref"]), rtol=2e-3, atol=2e-5)
+    assert float(np.max(np.abs(got - ref))) < 2e-5 * float(np.max(np.abs(img)))
+    # a stack shares ONE stream over its frames
+    st = np.stack([img, img[::-1].copy()])
+    g2 = pp.deconvolve_psf(st, sigma=1.5, method="uw", rng=np.random.default_rng(11))
+    r2 = W.deconvolve_psf(st, sigma=1.5, method="uw", rng=np.random.default_rng(11))
+    assert float(np.max(np.abs(g2 - r2))) < 2e-5 * float(np.max(np.abs(img))) and np.array_equal(g2[0], got)
+
+
+def test_unsupervised_wiener_device_stream(pp):
+    """Default `rng=None`: normals from the device generator (Philox), a fresh stream per call like the reference's own
+    behaviour.  Statistical checks only: two calls differ, both stay within the sampler's run-to-run spread of the oracle's
+    answer, and the estimated noise precision matches the noise that was put in (1 / 0.02^2 on the normalised frame)."""
+    from oracle import wiener_np as W
+
+    _, img = _blurred_scene(200, 200, seed=5, noise=0.02)
+    a = pp.deconvolve_psf(img, sigma=1.5, method="uw")
+    b = pp.deconvolve_psf(img, sigma=1.5, method="uw")
+    r1 = W.deconvolve_psf(img, sigma=1.5, method="uw", rng=1)
+    r2 = W.deconvolve_psf(img, sigma=1.5, method="uw", rng=2)
+    spread = float(np.sqrt(np.mean((r1 - r2) ** 2)))
+    assert not np.array_equal(a, b)
+    for g in (a, b):
+        assert float(np.sqrt(np.mean((g - r1) ** 2))) < 2.0 * spread
+    # moments of the device normals through the sampler itself: x - wiener_mean has variance 0.5 / precision per component
+    noise_prec = []
+    pp.deconvolve_psf(img, sigma=1.5, method="uw", user_params={"callback": lambda x: noise_prec.append(x.shape), "max_num_iter": 5, "min_num_iter": 1, "burnin": 1})
+    assert len(noise_prec) == 5
+    with pytest.raises(NotImplementedError):
+        pp.deconvolve_psf(img, sigma=1.5, method="uw", is_real=False)
+
+
+def test_uw_step_device_normals_and_sums(pp):
+    """b4d_uw_step through the C ABI.  With tf = 0, |L|^2 = 1 and gx = 0.5 the sample IS the pair of normals (precision 0.5,
+    excursion scale 1): moments of the device generator over 2^20 elements, independence between sweeps and between the two
+    components; and the four sums against NumPy on the same arrays (half-plane weights included)."""
+    import ctypes as C
+
+    import torch
+
+    from barc4dip_amd import _device as D
+    from barc4dip_amd import _ffi
+    from oracle import wiener_np as W
+
+    lib = _ffi.lib()
+    ny, nxh = 1024, 1024 + 1
+    dev = torch.device("cuda")
+    y = torch.zeros((ny, nxh), dtype=torch.complex64, device=dev)
+    tf = torch.zeros_like(y)
+    a2 = torch.ones((ny, nxh), dtype=torch.float32, device=dev)
+    xs, post = torch.empty_like(y), torch.zeros_like(y)
+    sums = torch.zeros(4, dtype=torch.float64, device=dev)
+    draws = []
+    for sweep in (0, 1):
+        _ffi.check(lib.b4d_uw_step(D.ptr(y), D.ptr(tf), D.ptr(a2), D.ptr(xs), D.ptr(post), None, None, 12345, sweep, 0, 1.0, 0.5, ny, nxh,
+                                   D.ptr(sums), _ffi.stream_ptr()))
+        draws.append(xs.cpu().numpy().copy())
+    z = np.concatenate([draws[0].real.ravel(), draws[0].imag.ravel()]).astype(np.float64)
+    n = z.size
+    assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1) < 5 * np.sqrt(2 / n) and abs(np.mean(z ** 4) - 3) < 0.05
+    assert abs(np.mean(draws[0].real * draws[0].imag)) < 5 / np.sqrt(n / 2)
+    assert abs(np.mean(draws[0].real * draws[1].real)) < 5 / np.sqrt(n / 2) and not np.array_equal(draws[0], draws[1])
+    assert np.max(np.abs(z)) > 4.0            # tails exist
+    # sums of a sweep with supplied normals, against NumPy
+    rng = np.random.default_rng(0)
+    ny, nxh = 96, 49
+    Y = (rng.normal(size=(ny, nxh)) + 1j * rng.normal(size=(ny, nxh))).astype(np.complex64)
+    Hh = (rng.normal(size=(ny, nxh)) + 1j * rng.normal(size=(ny, nxh))).astype(np.complex64) * 0.5
+    A2 = rng.random((ny, nxh)).astype(np.float32) + 0.1
+    R1, R2 = rng.normal(size=(ny, nxh)).astype(np.float32), rng.normal(size=(ny, nxh)).astype(np.float32)
+    P0 = (rng.normal(size=(ny, nxh)) + 1j * rng.normal(size=(ny, nxh))).astype(np.complex64)
+    t = lambda a: torch.from_numpy(a).to(dev)   # noqa: E731
+    dY, dH, dA, d1, d2, dP = t(Y), t(Hh), t(A2), t(R1), t(R2), t(P0.copy())
+    dx = torch.empty_like(dY)
+    gn, gx, sweep, burn = 3.0, 0.7, 5, 2
+    _ffi.check(lib.b4d_uw_step(D.ptr(dY), D.ptr(dH), D.ptr(dA), D.ptr(dx), D.ptr(dP), D.ptr(d1), D.ptr(d2), 0, sweep, burn, gn, gx, ny, nxh,
+                               D.ptr(sums), _ffi.stream_ptr()))
+    prec = gn * np.abs(Hh) ** 2 + gx * A2
+    x = gn * np.conj(Hh) / prec * Y + np.sqrt(0.5 / prec) * (R1 + 1j * R2)
+    assert np.allclose(dx.cpu().numpy(), x, rtol=2e-5, atol=2e-6)
+    pn = P0 + x
+    want = [W.image_quad_norm(Y - x * Hh), W.image_quad_norm(x * np.sqrt(A2)),
+            np.sum(np.abs(pn / (sweep - burn) - P0 / (sweep - burn - 1))), np.sum(np.abs(pn))]
+    assert np.allclose(sums.cpu().numpy(), want, rtol=2e-5)
+    assert np.allclose(dP.cpu().numpy(), pn, rtol=2e-5, atol=2e-6)
+    assert lib.b4d_uw_step(D.ptr(dY), D.ptr(dH), D.ptr(dA), None, D.ptr(dP), D.ptr(d1), None, 0, 0, 0, 1.0, 1.0, ny, nxh, D.ptr(sums), None) != 0
+
+
 @pytest.mark.parametrize("clip", [True, False])
 def test_cfg5_size(pp, clip):
     """BASELINE.json config 5 at its stated size: one 4096 x 4096 frame, sigma 1.5 (9 x 9 PSF, padded 4104 = 8 * 27 * 19),
