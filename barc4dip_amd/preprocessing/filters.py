@@ -128,7 +128,10 @@ def _uw_one_frame(frame, psf: np.ndarray, clip: bool, reg, user_params, rng):
         if tuple(L.shape) != (ny, nxh):
             raise ValueError(f"reg: a transfer function must have the half-plane shape {(ny, nxh)} of the padded frame")
     else:
-        L = ir2tf(np.asarray(reg, dtype=np.float32))
+        rk = np.asarray(reg, dtype=np.float32)
+        if rk.ndim != 2 or rk.shape[0] > ny or rk.shape[1] > nx:
+            raise ValueError("reg must be None, a 2-D impulse response no larger than the padded frame, or a complex transfer function")
+        L = ir2tf(rk)
     H = ir2tf(np.asarray(psf, dtype=np.float32))
     areg2 = (L.real * L.real + L.imag * L.imag).contiguous()
     Y = (half_spectrum(work) / float(np.sqrt(npix))).contiguous()          # unitary transform
