@@ -79,8 +79,12 @@ def laplacian_variance(image, *, verbose: bool = False) -> float:
     return var
 
 
-def _entropy_from(row, size: int, remove_dc: bool) -> float:
+def _entropy_from(row, size: int, remove_dc: bool, p_dc: float = 0.0) -> float:
+    """row: b4d_psd_stats sums over every bin but the DC one; p_dc: the DC bin's power where it takes part."""
     s_all, splnp = float(row[5]), float(row[6])
+    if p_dc > 0.0:
+        s_all += p_dc
+        splnp += p_dc * float(np.log(p_dc))
     if not np.isfinite(s_all) or s_all <= 0.0:
         raise ValueError("PSD sum is non-positive; cannot compute spectral entropy.")
     m = int(size - 1) if remove_dc else int(size)
@@ -95,10 +99,14 @@ def spectral_entropy(image, *, remove_mean: bool = True, remove_dc: bool = True,
     """Normalised Shannon entropy of the PSD (reference: sharpness.py:536-629; like the reference, the image is
     NOT padded to a square).  The eps clip of the reference changes the value by < 1e-27 and is not applied."""
     t = _check2d(image, "spectral_entropy", all_finite=True)
-    if not (remove_mean and remove_dc):
-        raise NotImplementedError("the GPU path implements the default remove_mean=True, remove_dc=True")
     psd = _fft.psd2d_stack(t[None], scale=False, return_tensors=True)
-    hn = _entropy_from(K.psd_stats_batch(psd)[0], int(t.numel()), remove_dc)
+    # Subtracting the mean changes the DC bin and nothing else, and the device sums leave that bin out: with the mean removed it
+    # holds rounding noise (< eps after the clip: nothing), zeroed it is gone, kept with the mean in it is (sum x)^2 exactly.
+    p_dc = 0.0
+    if not remove_mean and not remove_dc:
+        mom = K.moments_batch(_pad4(t[None]), eps=0.0, saturation=None).cpu().numpy()[0]
+        p_dc = float(mom[0] * mom[1]) ** 2
+    hn = _entropy_from(K.psd_stats_batch(psd)[0], int(t.numel()), remove_dc, p_dc)
     if verbose:
         logger.info("> spectral_entropy: %.6g", hn)
     return hn

@@ -347,3 +347,19 @@ def test_batched_stack_path_equals_per_frame(gm):
                 walk(res["tiles"], one["tiles"], "speckle/tiles")
                 walk(sh["full"], one_s["full"], "sharp/full")
                 walk(sh["tiles"], one_s["tiles"], "sharp/tiles")
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (100, 37), (512, 300)])
+def test_spectral_entropy_options(gm, shape):
+    """sharpness.py:536-629 with every combination of remove_mean / remove_dc (the defaults are covered by the KATs): the mean
+    only lives in the DC bin, so three of the four cases share the device sums and the fourth adds (sum x)^2."""
+    from oracle import metrics_np as M
+
+    rng = np.random.default_rng(shape[0] + shape[1])
+    img = (rng.poisson(40.0, size=shape) + rng.random(shape)).astype(np.float32)
+    for rm in (True, False):
+        for rd in (True, False):
+            want = M.spectral_entropy(img.astype(np.float64), remove_mean=rm, remove_dc=rd)
+            got = gm.sharpness.spectral_entropy(img, remove_mean=rm, remove_dc=rd)
+            assert got == pytest.approx(want, rel=2e-5), (rm, rd)
+    assert gm.sharpness.spectral_entropy(img, remove_mean=False, remove_dc=False) < 0.5 * gm.sharpness.spectral_entropy(img)
