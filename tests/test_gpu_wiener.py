@@ -230,7 +230,9 @@ def test_stack_balance_and_errors(pp):
     with pytest.raises(ValueError):
         pp.deconvolve_psf(stack, sigma=1.0, pad_mode="edge")
     with pytest.raises(NotImplementedError):
-        pp.deconvolve_psf(stack, sigma=1.0, method="uw")
+        pp.deconvolve_psf(stack, sigma=1.0, method="uw", is_real=False)
+    with pytest.raises(ValueError):
+        pp.deconvolve_psf(stack, sigma=1.0, method="uw", reg=0.5)     # the reference's own `reg: float` cannot work either
 
 
 def test_stack_frames_on_two_streams_keep_the_callers_order(pp):
@@ -280,5 +282,5 @@ def test_richardson_lucy_vs_oracle(pp, shape, sigma, iters):
     assert np.array_equal(out2[0], pp.deconvolve_psf(img, sigma=sigma, method="rl", num_iter=4))
     with pytest.raises(ValueError):
         pp.deconvolve_psf(img, sigma=sigma, method="rl", num_iter=0)
-    with pytest.raises(NotImplementedError):
-        pp.deconvolve_psf(img, sigma=sigma, method="uw")
+    with pytest.raises(ValueError):
+        pp.deconvolve_psf(img, sigma=sigma, method="richardson")
