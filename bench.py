@@ -29,6 +29,10 @@ import time
 
 import numpy as np
 
+# dmabuf IPC (the only mode the host driver of this pool supports): RCCL / cross-process tensor sharing fails with
+# "hipIpcGetMemHandle: invalid argument" without it.  The environment normally exports it already; this is a seat belt.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
