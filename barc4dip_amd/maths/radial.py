@@ -71,7 +71,14 @@ def radial_mean_interpolated(signal_2d, *, r_max=None, nr=None, ntheta=None, fil
             raise ValueError("signal_2d contains non-finite values.")
     if signal_2d.ndim != 2:
         raise ValueError("signal_2d must be a 2D array.")
-    if fill_value != 0.0:
-        raise NotImplementedError("the GPU radial profile implements fill_value=0.0 (the only value the package uses)")
     prof, r = radial_profile_batch(signal_2d[None], r_max=r_max, nr=nr, ntheta=ntheta)
+    if fill_value != 0.0:
+        # The kernel takes samples outside the grid as 0 (RegularGridInterpolator(bounds_error=False, fill_value=0)); any other
+        # fill value adds fill_value x (share of such samples) at every radius -- a function of the sampling geometry alone.
+        ny, nx = (int(v) for v in signal_2d.shape)
+        nt = int(2.0 * np.pi * 180.0) if ntheta is None else int(ntheta)
+        th = np.arange(nt, dtype=float) * (2.0 * np.pi / nt)
+        px, py = r[:, None] * np.cos(th)[None, :], r[:, None] * np.sin(th)[None, :]
+        outside = (px < -(nx // 2)) | (px > nx - 1 - nx // 2) | (py < -(ny // 2)) | (py > ny - 1 - ny // 2)
+        prof = prof + float(fill_value) * np.mean(outside, axis=1)[None, :]
     return prof[0], r

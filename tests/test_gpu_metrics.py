@@ -109,6 +109,13 @@ def test_percentiles_and_radial_vs_numpy(gm):
     pr, rr = M.radial_mean_interpolated(acs.astype(np.float32).astype(np.float64))
     np.testing.assert_allclose(prof, pr, rtol=1e-9, atol=1e-12)
     np.testing.assert_array_equal(r, rr)
+    # samples beyond the grid (r_max past the edge) with a non-zero fill value: maths/radial.py:163
+    rm = __import__("barc4dip_amd.maths", fromlist=["x"]).radial_mean_interpolated
+    for fill in (0.0, 2.5):
+        p2, r2 = rm(acs.astype(np.float32), r_max=80.0, nr=41, fill_value=fill)
+        q2, s2 = M.radial_mean_interpolated(acs.astype(np.float32).astype(np.float64), r_max=80.0, nr=41, fill_value=fill)
+        np.testing.assert_allclose(p2, q2, rtol=1e-9, atol=1e-12)
+        np.testing.assert_array_equal(r2, s2)
 
 
 def test_errors_match_reference(gm):

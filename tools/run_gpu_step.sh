@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r16
-timeout -k 10 1100 python -m pytest tests -q -m gpu > gpurun_out/r16/pytest.log 2>&1; tail -4 gpurun_out/r16/pytest.log
+mkdir -p gpurun_out/r18
+timeout -k 10 900 python -m pytest tests/test_gpu_metrics.py -x -q -m gpu > gpurun_out/r18/pytest.log 2>&1; tail -25 gpurun_out/r18/pytest.log
