@@ -29,12 +29,32 @@ __global__ void __launch_bounds__(256) k_roi_part(const float* __restrict__ fram
     const int h = sd.y1 - sd.y0, w = sd.x1 - sd.x0, n = h * w;
     const float* f = frames + (size_t)sd.frame * ny * nx;
     const double x0 = (double)f[(size_t)sd.y0 * nx + sd.x0];
-    const int per = (n + ROI_SPLIT - 1) / ROI_SPLIT, e0 = blockIdx.x * per, e1 = min(n, e0 + per);
+    // a slice = a range of ROI rows, walked row by row: no division per pixel (the flat-index form cost a full-frame source,
+    // 5.5 M pixels at 2160 x 2560, 160 us: a quarter of a small general-size tracking call), four rows in flight per lane
+    (void)n;
+    const int per = (h + ROI_SPLIT - 1) / ROI_SPLIT, r0 = blockIdx.x * per, r1 = min(h, r0 + per);
     double a1 = 0.0, a2 = 0.0;
-    for (int i = e0 + threadIdx.x; i < e1; i += 256) {
-        const double d = (double)f[(size_t)(sd.y0 + i / w) * nx + sd.x0 + i % w] - x0;
-        a1 += d;
-        a2 = fma(d, d, a2);
+    const float* base = f + (size_t)sd.y0 * nx + sd.x0;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        const float* q = base + (size_t)r * nx;
+        for (int x = threadIdx.x; x < w; x += 256) {
+            const double d0 = (double)q[x] - x0, d1 = (double)q[x + (size_t)nx] - x0, d2 = (double)q[x + 2 * (size_t)nx] - x0,
+                         d3 = (double)q[x + 3 * (size_t)nx] - x0;
+            a1 += (d0 + d1) + (d2 + d3);
+            a2 = fma(d0, d0, a2);
+            a2 = fma(d1, d1, a2);
+            a2 = fma(d2, d2, a2);
+            a2 = fma(d3, d3, a2);
+        }
+    }
+    for (; r < r1; ++r) {
+        const float* q = base + (size_t)r * nx;
+        for (int x = threadIdx.x; x < w; x += 256) {
+            const double d = (double)q[x] - x0;
+            a1 += d;
+            a2 = fma(d, d, a2);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
