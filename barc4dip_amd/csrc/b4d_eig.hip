@@ -391,7 +391,12 @@ __global__ void __launch_bounds__(1024) k_ritz(const double* __restrict__ partT,
         A0[p][q] = x;
         __syncthreads();
     }
-    for (int sweep = 0; sweep < RITZ_SWEEPS; ++sweep)
+    // A sweep in which no pair needed a rotation leaves the matrix as it is, and so would every later one: stop there (the
+    // Ritz matrix of a nearly converged subspace is nearly diagonal: 2-3 sweeps instead of the fixed 10, same bits out).
+    __shared__ int rotated;
+    for (int sweep = 0; sweep < RITZ_SWEEPS; ++sweep) {
+        if (threadIdx.x == 0) rotated = 0;
+        __syncthreads();
         for (int r = 0; r < NB - 1; ++r) {
             if (threadIdx.x < NB / 2) {
                 const int i = threadIdx.x;
@@ -405,6 +410,7 @@ __global__ void __launch_bounds__(1024) k_ritz(const double* __restrict__ partT,
                     const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                     c = 1.0 / sqrt(tt * tt + 1.0);
                     s_ = tt * c;
+                    rotated = 1;
                 }
                 cs[pp] = c;
                 cs[qq] = c;
@@ -419,6 +425,10 @@ __global__ void __launch_bounds__(1024) k_ritz(const double* __restrict__ partT,
             A0[p][q] = cs[q] * A1[p][q] + sg[q] * A1[p][partner[q]];  // columns
             __syncthreads();
         }
+        const int any = rotated;
+        __syncthreads();
+        if (!any) break;
+    }
     if (q == 0) {
         const double d = A0[p][p];
         int rank = 0;
@@ -446,7 +456,10 @@ __global__ void __launch_bounds__(1024) k_jacobi_small(const float* __restrict__
         A0[p][q] = (p < m && q < m) ? 0.5 * ((double)g[p * m + q] + (double)g[q * m + p]) : 0.0;
     }
     __syncthreads();
-    for (int sweep = 0; sweep < 12; ++sweep)
+    __shared__ int rotated;   // as in k_ritz: a sweep without a rotation ends the iteration
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        if (threadIdx.x == 0) rotated = 0;
+        __syncthreads();
         for (int r = 0; r < JS - 1; ++r) {
             if (threadIdx.x < JS / 2) {
                 const int i = threadIdx.x;
@@ -460,6 +473,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_small(const float* __restrict__
                     const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                     c = 1.0 / sqrt(tt * tt + 1.0);
                     s_ = tt * c;
+                    rotated = 1;
                 }
                 cs[pp] = c;
                 cs[qq] = c;
@@ -480,6 +494,10 @@ __global__ void __launch_bounds__(1024) k_jacobi_small(const float* __restrict__
             }
             __syncthreads();
         }
+        const int any = rotated;
+        __syncthreads();
+        if (!any) break;
+    }
     if (threadIdx.x < JS) {
         const int p = threadIdx.x;
         const double d = p < m ? A0[p][p] : -1e300;   // padding never ranks among the eigenvalues

@@ -1,10 +1,10 @@
-mkdir -p gpurun_out/r21
-timeout -k 10 900 python -m pytest tests/test_gpu_tracking.py tests/test_gpu_metrics.py -x -q -m gpu > gpurun_out/r21/pytest.log 2>&1; tail -4 gpurun_out/r21/pytest.log
-bash tools/prof_stats.sh r21/prof_gtrack2 tools/dev_general_track.py > /dev/null; python3 - <<'PY'
+mkdir -p gpurun_out/r22
+timeout -k 10 900 python -m pytest tests/test_gpu_metrics.py -x -q -m gpu > gpurun_out/r22/pytest.log 2>&1; tail -4 gpurun_out/r22/pytest.log
+timeout -k 10 300 python tools/dev_aggr_prof.py 2>&1 | grep -v amdgpu
+bash tools/prof_stats.sh r22/prof_aggr2 tools/dev_aggr_prof.py > /dev/null; python3 - <<'PY'
 import csv,glob
-f=sorted(glob.glob("gpurun_out/r21/prof_gtrack2/*/*kernel_stats.csv"))[-1]
-for r in list(csv.DictReader(open(f)))[:8]:
-    print(r["Name"][:60].ljust(60), r["Calls"], round(float(r["AverageNs"])/1e3,1), "us avg", r["Percentage"])
+f=sorted(glob.glob("gpurun_out/r22/prof_aggr2/*/*kernel_stats.csv"))[-1]
+rows=list(csv.DictReader(open(f)))
+for r in rows[:6]:
+    print(r["Name"][:72].ljust(72), r["Calls"], round(int(r["TotalDurationNs"])/1e3), "us", r["Percentage"])
 PY
-grep "pairs/s\|calls/s" gpurun_out/r21/prof_gtrack2.log
-timeout -k 10 300 python tools/bench_configs.py 3 | cut -c1-170
