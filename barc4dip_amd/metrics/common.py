@@ -86,14 +86,10 @@ def aggregate_subtiles_9x9_to_3x3(sub):
     arr = np.asarray(sub, dtype=float)
     if arr.shape != (9, 9):
         raise ValueError("Expected subtiles grid of shape (9, 9).")
-    mean = np.empty((3, 3))
-    std = np.empty((3, 3))
-    for r in range(3):
-        for c in range(3):
-            blk = arr[3 * r:3 * r + 3, 3 * c:3 * c + 3]
-            mean[r, c] = float(np.mean(blk))
-            std[r, c] = float(np.std(blk, ddof=0))
-    return mean, std
+    # block (r, c) = rows 3r..3r+2, columns 3c..3c+2 -> one (3, 3, 9) view, two reductions instead of eighteen (the stack
+    # aggregators call this once per field, tile group and frame: it was a fifth of their host time)
+    blocks = arr.reshape(3, 3, 3, 3).transpose(0, 2, 1, 3).reshape(3, 3, 9)
+    return blocks.mean(axis=-1), blocks.std(axis=-1)
 
 
 def tile_spans(h: int, w: int, tile_mode: str):

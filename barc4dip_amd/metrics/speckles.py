@@ -21,7 +21,8 @@ from .. import _device as D
 from .. import _ffi
 from ..geometry.roi import odd_size, roi_grid_3x3
 from ..maths.radial import radial_mean_binned, radial_profile_batch
-from ..maths.stats import distance_at_fraction_from_peak, width_at_fraction
+from ..maths.stats import (distance_at_fraction_from_peak, distances_at_fraction_from_peak_batch, width_at_fraction,
+                           widths_at_fraction_batch)
 from ..signal import corr as _corr
 from ..signal import fft as _fft
 from ..signal.tracking import phase_correlation_batch, template_matching_batch
@@ -146,13 +147,10 @@ def _widths_batch(ac, fraction: float):
     dr = float(r[1] - r[0])
     if dr <= 0:
         raise ValueError("Invalid radial sampling (non-positive dr).")
-    out = []
-    for i in range(b):
-        ly, _ = width_at_fraction(y_cuts[i], fraction=fraction, center_index=int(iy[i]))
-        lx, _ = width_at_fraction(x_cuts[i], fraction=fraction, center_index=int(ix[i]))
-        dist, _ = distance_at_fraction_from_peak(rad[i], fraction=fraction, peak_index=0)
-        out.append((float(lx), float(ly), 2 * float(dist) * dr))
-    return out
+    ly, _ = widths_at_fraction_batch(y_cuts, iy, fraction=fraction)
+    lx, _ = widths_at_fraction_batch(x_cuts, ix, fraction=fraction)
+    dist, _ = distances_at_fraction_from_peak_batch(rad, fraction=fraction, peak_index=0)
+    return [(float(lx[i]), float(ly[i]), 2 * float(dist[i]) * dr) for i in range(b)]
 
 
 def _grain_batch(stack, fraction: float = 1.0 / np.e) -> list[dict]:

@@ -1,2 +1,3 @@
-mkdir -p gpurun_out/r23
-timeout -k 10 600 python tools/dev_soak_routes.py 5 150 > gpurun_out/r23/soak_routes.log 2>&1; tail -6 gpurun_out/r23/soak_routes.log
+mkdir -p gpurun_out/r24
+timeout -k 10 900 python -m pytest tests/test_gpu_metrics.py -x -q -m gpu > gpurun_out/r24/pytest.log 2>&1; tail -4 gpurun_out/r24/pytest.log
+timeout -k 10 300 python tools/dev_stack_prof.py 2>&1 | grep -v amdgpu
