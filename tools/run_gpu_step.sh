@@ -1,3 +1,5 @@
-mkdir -p gpurun_out/r24
-timeout -k 10 300 python tools/dev_stack_cprof.py speckle > gpurun_out/r24/cprof_speckle2.log 2>&1; grep -v amdgpu gpurun_out/r24/cprof_speckle2.log | head -40 | cut -c1-150
-timeout -k 10 300 python tools/dev_stack_cprof.py sharp > gpurun_out/r24/cprof_sharp.log 2>&1; grep -v amdgpu gpurun_out/r24/cprof_sharp.log | head -36 | cut -c1-150
+# scratch driver for one gpurun call: the GPU tier of the tests, the smoke check and the default bench line
+mkdir -p gpurun_out/step
+timeout -k 10 1100 python -m pytest tests -q -m gpu > gpurun_out/step/pytest.log 2>&1; tail -4 gpurun_out/step/pytest.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/step/smoke.log 2>&1; tail -1 gpurun_out/step/smoke.log
+timeout -k 10 600 python bench.py > gpurun_out/step/bench.json 2> gpurun_out/step/bench.err; echo "bench rc $?"; tail -c 400 gpurun_out/step/bench.json
