@@ -235,18 +235,20 @@ def test_phase_correlation_general_sizes(gs, shape):
         assert got[2] == pytest.approx(want[2], rel=1e-3) and got[3] == pytest.approx(want[3], rel=2e-3)
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (128, 256), (2048, 512), (512, 2048), (2048, 2048), (4096, 1024)])
+@pytest.mark.parametrize("shape", [(64, 64), (128, 256), (2048, 512), (512, 2048), (2048, 2048), (4096, 1024),
+                                   (600, 720), (1080, 1920), (767, 1024), (1024, 768)])   # the last four: mixed-radix kernels (767: fused route)
 def test_phase_correlation_power_of_two_sizes_all_routes(gs, shape):
     """Every row-kernel geometry of the power-of-two route (1 to 32 row pairs per workgroup, 1 to 3 workgroups for the rows
-    around the peak) with the median expectation on (map-free pass + rows around the peak), off (full map) and deliberately
-    wrong (gated full-map pass): bit-identical rows, and parity with the float64 oracle."""
+    around the peak) and the mixed-radix route (quads of row pairs, odd heights) with the median expectation on (map-free pass
+    + rows around the peak), off (full map) and deliberately wrong (gated full-map pass): bit-identical rows, and parity with
+    the float64 oracle."""
     from barc4dip_amd import _ffi
     from oracle import signal_np as S
 
     H, W = shape
     rng = np.random.default_rng(H * 3 + W)
     base = synth_frame(max(H, W), 11)[:H, :W]
-    big = 121 if max(H, W) >= 2048 else 41   # (a 41 x 61 template is lost in the noise of a 4096 x 1024 frame: the reference's own answer)
+    big = 121 if max(H, W) >= 1024 else 41   # (a 41 x 61 template is lost in the noise of a 4096 x 1024 frame: the reference's own answer)
     h, w = min(big, H // 2 - 1) | 1, min(big + 20, W // 2 - 1) | 1
     dy, dx = max(-5, -(H // 8)), min(9, W // 8)
     fr = (np.roll(base, (dy, dx), axis=(0, 1)) + rng.normal(size=(H, W)) * 5).astype(np.float32)
