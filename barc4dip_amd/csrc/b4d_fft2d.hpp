@@ -456,7 +456,14 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
             c[2 * h] = make_float2(0.5f * (z.x + zr.x), 0.5f * (z.y - zr.y));
             c[2 * h + 1] = make_float2(0.5f * (z.y + zr.y), 0.5f * (zr.x - z.x));
         }
-        if (!p.half_rows || u2 + T * j <= NY / 2 + 1) store_cols<NC>(at_bytes<f32x2>(sgpr_base(tile + (size_t)(T * j * CT)), toff2 * 8u), c);
+        // streaming (non-temporal) stores: the tile is read once more, by the row pass, after a gigabyte of other traffic -- kept
+        // out of L2 it leaves the cache to the PSD half lines that do meet there (-3 % on this kernel; the PSD stores themselves
+        // must stay cached: non-temporal they doubled the kernel)
+        if (!p.half_rows || u2 + T * j <= NY / 2 + 1) {
+            static_assert(NC == 2, "one 16-byte store per row");
+            __builtin_nontemporal_store(f32x4{c[0].x, c[0].y, c[1].x, c[1].y},
+                                        (f32x4 B4D_GLOBAL*)at_bytes<f32x2>(sgpr_base(tile + (size_t)(T * j * CT)), toff2 * 8u));
+        }
     }
     B4D_STAMP(6);
     B4D_DRAIN();
@@ -641,7 +648,10 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
     for (int j = 0; j < E / 2; ++j) {
         const int k = u + T * j;
         const size_t o = spec_index(frame, nt, ny, ct_w, yl, k);
-        const float2 a = p.g[o], b = p.g[o + ct_w];
+        // read once, written once: streaming hints on both sides of the row pass (-4 % on the cfg2 kernel)
+        const f32x2 a_ = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.g + o)),
+                    b_ = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.g + o + ct_w));
+        const float2 a = make_float2(a_.x, a_.y), b = make_float2(b_.x, b_.y);
         if (k == 0) {  // DC and Nyquist bins of both rows are real
             v[j] = make_float2(b.x, a.x);                                                       // swap(A_dc + i B_dc)
             lds[NX / 2] = make_float2(p.gnyq[frame * ny + yl + 1], p.gnyq[frame * ny + yl]);  // swap(A_nyq + i B_nyq)
@@ -685,10 +695,10 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
             float r0 = v[j].y * s;
             const float r1 = v[j].x * s;
             if (unit_peak && pair == 0 && x == 0) r0 = 1.0f;  // peak normalisation: zero lag is 1 by definition
-            o0[c] = r0;
-            if (wr1) o1[c] = r1;
-            if (mir0) q0[cm] = r0;
-            if (mir1) q1[cm] = r1;
+            __builtin_nontemporal_store(r0, o0 + c);
+            if (wr1) __builtin_nontemporal_store(r1, o1 + c);
+            if (mir0) __builtin_nontemporal_store(r0, q0 + cm);
+            if (mir1) __builtin_nontemporal_store(r1, q1 + cm);
         }
         return;
     }
