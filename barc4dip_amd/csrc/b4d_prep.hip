@@ -52,6 +52,45 @@ __global__ void __launch_bounds__(256) k_flat_field(const float* __restrict__ im
     out[o] = v;
 }
 
+// 16-byte variant: a lane keeps the flat / dark values of its four pixels in registers and walks the frames of a slice of the
+// batch (frame words are read and written once: streaming loads / stores).  Same per-element arithmetic as k_flat_field.
+// grid (ceil(npix / 4 / 256), slices)
+__global__ void __launch_bounds__(256) k_flat_field4(const float* __restrict__ img, const float* __restrict__ flat,
+                                                     const float* __restrict__ dark, size_t npix, int batch, float eps, float scale,
+                                                     int apply_scale, float* __restrict__ out) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= npix) return;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    const v4f d = dark ? *reinterpret_cast<const v4f*>(dark + i) : zero;
+    v4f den = zero;
+    if (flat) {
+        const v4f fl = *reinterpret_cast<const v4f*>(flat + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) den[k] = __fsub_rn(fl[k], d[k]);
+    }
+    const int per = (batch + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(batch, b0 + per);
+    for (int b = b0; b < b1; ++b) {
+        const size_t o = (size_t)b * npix + i;
+        const v4f x = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(img + o));
+        v4f r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float num = dark ? __fsub_rn(x[k], d[k]) : x[k];
+            float v = num;
+            if (flat) {
+                v = 0.f;
+                if (!(den[k] <= eps)) {
+                    v = __fdiv_rn(num, den[k]);
+                    if (apply_scale) v = __fmul_rn(v, scale);
+                }
+            }
+            r[k] = v;
+        }
+        __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(out + o));
+    }
+}
+
 __device__ __forceinline__ void cswap_minmax(float& a, float& b) {
     const float lo = fminf(a, b), hi = fmaxf(a, b);
     a = lo;
@@ -121,8 +160,18 @@ extern "C" int b4d_flat_den(const float* flat, const float* dark, size_t npix, f
 extern "C" int b4d_flat_field(const float* frames, int batch, size_t npix, const float* flat, const float* dark, float eps, float scale,
                               int apply_scale, float* out, void* stream) {
     if (!frames || !out || batch < 1 || npix < 1 || (!flat && !dark)) return fail(B4D_EINVAL, "b4d_flat_field: bad argument");
-    hipLaunchKernelGGL(k_flat_field, dim3((unsigned)((npix + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, frames, flat, dark, npix,
-                       eps, scale, apply_scale, out);
+    const bool vec = (npix & 3) == 0 && ((reinterpret_cast<uintptr_t>(frames) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(flat) |
+                                          reinterpret_cast<uintptr_t>(dark)) & 15) == 0;
+    if (vec) {
+        const unsigned gx = (unsigned)((npix / 4 + 255) / 256);
+        // enough workgroups to fill the chip several times over, as few batch slices as that takes (flat / dark are re-read per slice)
+        const int slices = (int)std::min<size_t>((size_t)batch, std::max<size_t>(1, (size_t)8192 / std::max(1u, gx)));
+        hipLaunchKernelGGL(k_flat_field4, dim3(gx, slices), dim3(256), 0, (hipStream_t)stream, frames, flat, dark, npix, batch, eps, scale,
+                           apply_scale, out);
+    } else {
+        hipLaunchKernelGGL(k_flat_field, dim3((unsigned)((npix + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, frames, flat, dark, npix,
+                           eps, scale, apply_scale, out);
+    }
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
