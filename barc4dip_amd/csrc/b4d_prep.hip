@@ -138,6 +138,36 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_to_f32(const T* __restrict__ src, size_t n, float* __restrict__ dst) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
 }
+// 16 source bytes per lane and iteration (16 / 8 / 4 elements for 1- / 2- / 4-byte words), streaming loads and stores: detector
+// words are converted once.  src and dst 16-byte aligned; the tail (n % V) goes through k_to_f32.
+template <typename T>
+__global__ void __launch_bounds__(256) k_to_f32_vec(const T* __restrict__ src, size_t nvec, float* __restrict__ dst) {
+    constexpr int V = 16 / sizeof(T);
+    typedef T srcv __attribute__((ext_vector_type(V)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const srcv q = __builtin_nontemporal_load(reinterpret_cast<const srcv*>(src) + i);
+        float* o = dst + i * V;
+#pragma unroll
+        for (int k = 0; k < V; k += 4)
+            __builtin_nontemporal_store(v4f{(float)q[k], (float)q[k + 1], (float)q[k + 2], (float)q[k + 3]}, reinterpret_cast<v4f*>(o + k));
+    }
+}
+template <typename T>
+static void launch_to_f32(const T* src, size_t n, float* dst, hipStream_t st) {
+    constexpr size_t V = 16 / sizeof(T);
+    size_t done = 0;
+    if constexpr (sizeof(T) <= 4) {
+        if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && n >= V) {
+            const size_t nvec = n / V;
+            hipLaunchKernelGGL(k_to_f32_vec<T>, dim3((unsigned)std::min<size_t>((nvec + 255) / 256, 65535)), dim3(256), 0, st, src, nvec, dst);
+            done = nvec * V;
+        }
+    }
+    if (done < n)
+        hipLaunchKernelGGL(k_to_f32<T>, dim3((unsigned)std::min<size_t>((n - done + 255) / 256, 65535)), dim3(256), 0, st, src + done, n - done,
+                           dst + done);
+}
 
 }  // namespace b4d
 
@@ -195,15 +225,14 @@ extern "C" int b4d_repair_pixels(float* frames, int batch, int ny, int nx, const
 extern "C" int b4d_to_f32(const void* src, int dtype, size_t n, float* dst, void* stream) {
     if (!src || !dst || n < 1) return fail(B4D_EINVAL, "b4d_to_f32: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 65535)), block(256);
     switch (dtype) {
-        case 0: hipLaunchKernelGGL(k_to_f32<unsigned char>, grid, block, 0, st, static_cast<const unsigned char*>(src), n, dst); break;
-        case 1: hipLaunchKernelGGL(k_to_f32<unsigned short>, grid, block, 0, st, static_cast<const unsigned short*>(src), n, dst); break;
-        case 2: hipLaunchKernelGGL(k_to_f32<short>, grid, block, 0, st, static_cast<const short*>(src), n, dst); break;
-        case 3: hipLaunchKernelGGL(k_to_f32<int>, grid, block, 0, st, static_cast<const int*>(src), n, dst); break;
-        case 4: hipLaunchKernelGGL(k_to_f32<unsigned int>, grid, block, 0, st, static_cast<const unsigned int*>(src), n, dst); break;
-        case 5: hipLaunchKernelGGL(k_to_f32<float>, grid, block, 0, st, static_cast<const float*>(src), n, dst); break;
-        case 6: hipLaunchKernelGGL(k_to_f32<double>, grid, block, 0, st, static_cast<const double*>(src), n, dst); break;
+        case 0: launch_to_f32(static_cast<const unsigned char*>(src), n, dst, st); break;
+        case 1: launch_to_f32(static_cast<const unsigned short*>(src), n, dst, st); break;
+        case 2: launch_to_f32(static_cast<const short*>(src), n, dst, st); break;
+        case 3: launch_to_f32(static_cast<const int*>(src), n, dst, st); break;
+        case 4: launch_to_f32(static_cast<const unsigned int*>(src), n, dst, st); break;
+        case 5: launch_to_f32(static_cast<const float*>(src), n, dst, st); break;
+        case 6: launch_to_f32(static_cast<const double*>(src), n, dst, st); break;
         default: return fail(B4D_EINVAL, "b4d_to_f32: dtype code must be 0..6 (u8, u16, i16, i32, u32, f32, f64)");
     }
     B4D_HIP(hipGetLastError());

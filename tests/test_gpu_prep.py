@@ -90,3 +90,31 @@ def test_nan_semantics(prep):
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).all()
     z = np.zeros_like(img)
     assert np.array_equal(prep.deconvolve_psf(z, sigma=1.0), W.deconvolve_psf(z, sigma=1.0))
+
+
+def test_to_f32_every_dtype_aligned_and_not(prep):
+    """b4d_to_f32 (images.astype(np.float32), normalize.py:79 / the ingest path): every detector word type, lengths with a tail
+    behind the 16-byte vector part, and a source view that starts off a 16-byte boundary (scalar kernel)."""
+    import ctypes as C
+
+    import torch
+
+    from barc4dip_amd import _ffi
+
+    lib = _ffi.lib()
+    rng = np.random.default_rng(0)
+    kinds = [(np.uint8, 0), (np.uint16, 1), (np.int16, 2), (np.int32, 3), (np.uint32, 4), (np.float32, 5), (np.float64, 6)]
+    for dt, code in kinds:
+        for n, off in ((1, 0), (37, 0), (4096 + 5, 0), (100003, 0), (4096 + 5, 1)):
+            if np.issubdtype(dt, np.integer):
+                info = np.iinfo(dt)
+                host = rng.integers(info.min, info.max, size=n + off, endpoint=True, dtype=dt)
+            else:
+                host = (rng.normal(size=n + off) * 1e3).astype(dt)
+            raw = torch.from_numpy(host.view(np.uint8).copy()).cuda()
+            src_ptr = raw.data_ptr() + off * host.itemsize
+            out = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+            _ffi.check(lib.b4d_to_f32(C.c_void_p(src_ptr), code, n, C.c_void_p(out.data_ptr()), None))
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), host[off:].astype(np.float32)), (dt, n, off)
+    assert lib.b4d_to_f32(C.c_void_p(raw.data_ptr()), 9, 4, C.c_void_p(out.data_ptr()), None) != 0
