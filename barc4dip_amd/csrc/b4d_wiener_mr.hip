@@ -695,8 +695,8 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_out(const float2*
                 const float* prow = mine + e * g.Wh;
                 for (int kx = ltq; kx < g.Wh; kx += L) {
                     const float v = prow[kx] * psd_scale;
-                    drow[(kx + g.W / 2) % g.W] = v;
-                    if (kx > 0 && 2 * kx != g.W) mrow[(g.W - kx + g.W / 2) % g.W] = v;
+                    __builtin_nontemporal_store(v, drow + (kx + g.W / 2) % g.W);   // outputs are written once: streaming stores
+                    if (kx > 0 && 2 * kx != g.W) __builtin_nontemporal_store(v, mrow + (g.W - kx + g.W / 2) % g.W);
                 }
             }
             __syncthreads();
@@ -747,8 +747,8 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_out(const float2*
             const float vb = -z.y * se;   // conj(buf): real part row a, imaginary part row b
             if (unit && r0 == 0 && x == 0) va = 1.0f;
             const int c = (x + g.W / 2) % g.W;
-            if (act) rowa[c] = va;
-            if (has_b) rowb[c] = vb;
+            if (act) __builtin_nontemporal_store(va, rowa + c);
+            if (has_b) __builtin_nontemporal_store(vb, rowb + c);
         }
         __syncthreads();
     }
