@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 N = 2048
 FRAMES_PER_GPU = 256
+BENCH_CHUNK = 256              # frames per launch group of the plan the bench creates (see main())
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 PMC_FILE = "profiles/r02_pmc_col.json"
 
@@ -298,7 +299,10 @@ def main():
     stack = synth.speckle_stack_device(T, N, seed0=1234 + 100000 * rank)
     psd = torch.empty_like(stack)
     ac = torch.empty_like(stack)
-    chunk = args.chunk or _ffi.default_chunk(N, N)
+    # frames per launch group: the whole per-GPU stack (plan workspace 16.8 MB per frame = 4.3 GB of the 288 GB).  The library
+    # default for this size is 64 (1 GiB of workspace for callers who did not ask): measured 43.7-44.0 k frames/s against
+    # 45.2-45.7 k with 128-256 frames per group -- the column pass walks 16 384 tiles per launch instead of 4 096.
+    chunk = args.chunk or min(T, BENCH_CHUNK)
     plan = _ffi.Plan(N, N, chunk)
     lib = _ffi.lib()
     kms = (C.c_float * 4)()
@@ -372,9 +376,14 @@ def main():
         pmc_path = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                pmc_frames = float(pmc.get("frames_per_launch", 64))
+                traffic = pmc.get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic = traffic * frames_per_launch / pmc_frames      # counters are per launch: same launch size as `achieved`
                 traffic_source = (f"{PMC_FILE} (static: a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of this bench at "
-                                  "64 frames per launch, NOT measured by the process that printed this line)")
+                                  f"{pmc_frames:.0f} frames per launch, scaled to this run's {frames_per_launch:.0f}; NOT measured by the "
+                                  "process that printed this line)")
             except Exception:
                 traffic = None
         line = {

@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $GRA
 cd $GRAFT_REPO_ROOT
 bash tools/pmc_run.sh $O/pmc_fetch FETCH_SIZE < /dev/null
 bash tools/pmc_run.sh $O/pmc_write WRITE_SIZE < /dev/null
-python3 tools/pmc_to_json.py $O/pmc_fetch $O/pmc_write 64 $O/pmc_col.json > $O/pmc_col.log 2>&1
+python3 tools/pmc_to_json.py $O/pmc_fetch $O/pmc_write 256 $O/pmc_col.json > $O/pmc_col.log 2>&1
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1)
 if [ -n "$f" ]; then cp $f $O/kernel_stats.csv; head -8 $f | cut -c1-160; fi
 cat $O/pmc_col.log | head -30

@@ -4,4 +4,4 @@
 set -e
 OUT=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --frames 64 --no-cpu --no-secondary > "$OUT.json" 2> "$OUT.err"
+rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --frames 256 --no-cpu --no-secondary > "$OUT.json" 2> "$OUT.err"

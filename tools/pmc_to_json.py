@@ -37,6 +37,7 @@ def main():
         res[tag] = {"FETCH_SIZE_KB_raw": f[0], "WRITE_SIZE_KB": w[0], "hbm_bytes_per_launch": (2 * f[0] + w[0]) * 1024,
                     "algorithmic_bytes_per_launch": alg[tag], "traffic_over_algorithmic": (2 * f[0] + w[0]) * 1024 / alg[tag]}
     res["hbm_bytes_per_launch"] = res.get("k_col", {}).get("hbm_bytes_per_launch")
+    res["frames_per_launch"] = frames
     res["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --frames %d --steps 2` (one launch = %d "
                    "frames of 2048x2048); FETCH_SIZE doubled (gfx950 reports 1/2 of streamed read bytes, MI355X_MICROARCH.md)." % (frames, frames))
     json.dump(res, open(out, "w"), indent=1)
