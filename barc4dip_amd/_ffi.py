@@ -184,6 +184,22 @@ def default_chunk(ny: int, nx: int) -> int:
     return max(1, min(chunk, cap, 128))
 
 
+def stack_chunk(ny: int, nx: int, frames: int) -> int:
+    """Launch group for the stack entry points (psd2d_stack / autocorr2d_stack / psd_autocorr2d_stack) on power-of-two frames:
+    the default group, or up to four times as many frames when the stack is that long and the workspace stays under 4.5 GiB
+    (2048^2: 64 -> 256 frames, 4.3 GB of a 288 GB device) -- the column pass runs 5-7 % faster on 16 384 tiles per launch than
+    on 4 096.  Per-frame calls, tracking and general-size plans keep the default (their work buffers scale with it)."""
+    base = default_chunk(ny, nx)
+    pow2 = lambda n: 64 <= n <= 4096 and n & (n - 1) == 0  # noqa: E731
+    if not (pow2(int(ny)) and pow2(int(nx))) or frames <= base or int(ny) * int(nx) < (1 << 20):
+        return base     # (measured at 512^2: 666 k frames/s with the default 128, 645 k with 512; 1024^2: 171 -> 185 k; 4096^2: 9.0 -> 9.3 k)
+    cap = max(1, int(4.5 * (1 << 30)) // (int(ny) * int(nx) * 4))
+    for mult in (2, 4):     # two sizes beyond the default, so that stacks of every length share three cached plans
+        if frames <= mult * base or mult == 4:
+            return max(base, min(mult * base, cap))
+    return base
+
+
 def get_plan(ny: int, nx: int, chunk: int | None = None, general: bool = False) -> Plan:
     import torch
 

@@ -105,7 +105,7 @@ def autocorr2d_stack(stack, *, remove_mean: bool = True, standardize: bool = Fal
     t, _, _ = D.to_device_f32(stack, ndim=(3,))
     T, ny, nx = t.shape
     flags = _flags(remove_mean, normalize)
-    pl = _ffi.get_plan(ny, nx)
+    pl = _ffi.get_plan(ny, nx, _ffi.stack_chunk(ny, nx, int(T)))
     out = torch.empty((T, ny, nx), dtype=torch.float32, device=t.device)
     _ffi.check(_ffi.lib().b4d_autocorr2d(pl.handle, D.ptr(t), int(T), D.ptr(out), flags, _ffi.stream_ptr()))
     if standardize and normalize == "none":
@@ -124,7 +124,7 @@ def psd_autocorr2d_stack(stack, *, dx: float = 1.0, dy: float = 1.0, scale: bool
     t, _, _ = D.to_device_f32(stack, ndim=(3,))
     T, ny, nx = t.shape
     flags = _flags(remove_mean, normalize)
-    pl = _ffi.get_plan(ny, nx)
+    pl = _ffi.get_plan(ny, nx, _ffi.stack_chunk(ny, nx, int(T)))
     psd = out_psd if out_psd is not None else torch.empty((T, ny, nx), dtype=torch.float32, device=t.device)
     ac = out_autocorr if out_autocorr is not None else torch.empty((T, ny, nx), dtype=torch.float32, device=t.device)
     s = (dx * dy) / (float(nx) * float(ny)) if scale else 1.0

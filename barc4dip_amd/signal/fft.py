@@ -150,7 +150,7 @@ def psd2d_stack(stack, *, dx: float = 1.0, dy: float = 1.0, scale: bool = True, 
     torch = _ffi.require_gpu()
     t, _, src = _frames(stack, (3,))
     T, ny, nx = t.shape
-    pl = _ffi.get_plan(ny, nx)
+    pl = _ffi.get_plan(ny, nx, _ffi.stack_chunk(ny, nx, int(T)))
     out = torch.empty((T, ny, nx), dtype=torch.float32, device=t.device)
     s = (dx * dy) / (float(nx) * float(ny)) if scale else 1.0
     _ffi.check(_ffi.lib().b4d_psd2d(pl.handle, D.ptr(t), int(T), D.ptr(out), float(s), _ffi.stream_ptr()))
