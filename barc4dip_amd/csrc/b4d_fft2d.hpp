@@ -75,17 +75,22 @@ struct RowSrc {
     int pad;
 };
 
-// grid (ceil(ny/2/SEQ), batch); block T*SEQ.  ct_w = tile width (complex columns) of the spectrum layout.
-template <int NX, int SEQ, bool SRC>
+// grid (ceil(ny/2/(SEQ*ITER)), batch); block T*SEQ.  ct_w = tile width (complex columns) of the spectrum layout.
+// ITER > 1 (full frames only): a workgroup transforms ITER consecutive groups of SEQ row pairs and issues the loads of ALL of
+// them before the first transform -- ITER x the bytes in flight per workgroup at the same LDS footprint (the exchange buffer,
+// not the register file, caps this kernel at four workgroups per CU).
+#ifndef B4D_K1_ITER
+#define B4D_K1_ITER 1
+#endif
+template <int NX, int SEQ, bool SRC, int ITER = 1>
 __global__ void __launch_bounds__((NX / E16) * SEQ)
 k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, float* __restrict__ nyq_rows,
           const float2* __restrict__ tw, int ny, int ct_w, const RowSrc* __restrict__ srcs) {
     using G = RowGeom<NX>;
     constexpr int T = G::T, E = E16;
+    static_assert(ITER == 1 || !SRC, "ROI sources run one group per workgroup");
     __shared__ float2 lds_all[SEQ * G::LDS_ELEMS];
     const int seq = threadIdx.x / T, u = threadIdx.x % T;
-    const int pair = blockIdx.x * SEQ + seq;
-    const bool live = 2 * pair < ny;  // ragged last workgroup: idle transforms still take part in the barriers
     const size_t frame = blockIdx.y;
     if (SRC) {   // rows outside the ROI are zero: a workgroup without a ROI row writes NOTHING -- the column pass and k_nyq
                  // know the ROI rows (ColArgs::srcs / NyqArgs::srcs) and never read the others (a 121-px template in a
@@ -94,52 +99,66 @@ k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, float* __rest
         if (wb <= srcs[frame].y0 || wa >= srcs[frame].y1) return;
     }
     float2* lds = lds_all + seq * G::LDS_ELEMS;
-    float2 v[E];
-    if (!live) {
+    float2 va[ITER][E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) v[j] = make_float2(0.f, 0.f);
-    } else if (SRC) {
-        const RowSrc sd = srcs[frame];
-        const int ya = 2 * pair, yb = ya + 1;
-        const bool ina = ya >= sd.y0 && ya < sd.y1, inb = yb >= sd.y0 && yb < sd.y1;
-        const float* r0 = in + ((size_t)sd.frame * ny + ya) * NX;
-        const float* r1 = r0 + NX;
+    for (int it = 0; it < ITER; ++it) {
+        float2(&v)[E] = va[it];
+        const int pair = (blockIdx.x * ITER + it) * SEQ + seq;
+        const bool live = 2 * pair < ny;  // ragged last workgroup: idle transforms still take part in the barriers
+        if (!live) {
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const int x = u + T * j;
-            const bool inx = x >= sd.x0 && x < sd.x1;
-            v[j].x = (ina && inx) ? (r0[x] - sd.mean) / sd.denom : 0.f;
-            v[j].y = (inb && inx) ? (r1[x] - sd.mean) / sd.denom : 0.f;
+            for (int j = 0; j < E; ++j) v[j] = make_float2(0.f, 0.f);
+        } else if (SRC) {
+            const RowSrc sd = srcs[frame];
+            const int ya = 2 * pair, yb = ya + 1;
+            const bool ina = ya >= sd.y0 && ya < sd.y1, inb = yb >= sd.y0 && yb < sd.y1;
+            const float* r0 = in + ((size_t)sd.frame * ny + ya) * NX;
+            const float* r1 = r0 + NX;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const int x = u + T * j;
+                const bool inx = x >= sd.x0 && x < sd.x1;
+                v[j].x = (ina && inx) ? (r0[x] - sd.mean) / sd.denom : 0.f;
+                v[j].y = (inb && inx) ? (r1[x] - sd.mean) / sd.denom : 0.f;
+            }
+        } else {
+            const float* r0 = in + (frame * ny + 2 * (size_t)pair) * NX;
+            const float* r1 = r0 + NX;
+#pragma unroll
+            for (int j = 0; j < E; ++j) v[j] = make_float2(r0[u + T * j], r1[u + T * j]);
         }
-    } else {
-        const float* r0 = in + (frame * ny + 2 * (size_t)pair) * NX;
-        const float* r1 = r0 + NX;
-#pragma unroll
-        for (int j = 0; j < E; ++j) v[j] = make_float2(r0[u + T * j], r1[u + T * j]);
     }
-    Fft3<G, 1>::run(v, v, u, 0, lds, tw);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < E; ++j) lds[u + T * j] = v[j];
-    __syncthreads();
     const int nt = (NX / 2) / ct_w;
-    if (!live) return;
 #pragma unroll
-    for (int j = 0; j < E / 2; ++j) {
-        const int k = u + T * j;
-        const float2 z = v[j], zr = lds[(NX - k) & (NX - 1)];
-        float2 a = make_float2(0.5f * (z.x + zr.x), 0.5f * (z.y - zr.y));
-        float2 b = make_float2(0.5f * (z.y + zr.y), 0.5f * (zr.x - z.x));
-        if (k == 0) {  // DC bins are real; the (real) Nyquist bins of both rows go to the side array
-            const float2 zn = lds[NX / 2];
-            a = make_float2(z.x, 0.f);
-            b = make_float2(z.y, 0.f);
-            nyq_rows[frame * ny + 2 * pair] = zn.x;
-            nyq_rows[frame * ny + 2 * pair + 1] = zn.y;
+    for (int it = 0; it < ITER; ++it) {
+        float2(&v)[E] = va[it];
+        const int pair = (blockIdx.x * ITER + it) * SEQ + seq;
+        const bool live = 2 * pair < ny;
+        if (it > 0) __syncthreads();   // the previous group's Hermitian split has read the buffer
+        Fft3<G, 1>::run(v, v, u, 0, lds, tw);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < E; ++j) lds[u + T * j] = v[j];
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < E / 2; ++j) {
+                const int k = u + T * j;
+                const float2 z = v[j], zr = lds[(NX - k) & (NX - 1)];
+                float2 a = make_float2(0.5f * (z.x + zr.x), 0.5f * (z.y - zr.y));
+                float2 b = make_float2(0.5f * (z.y + zr.y), 0.5f * (zr.x - z.x));
+                if (k == 0) {  // DC bins are real; the (real) Nyquist bins of both rows go to the side array
+                    const float2 zn = lds[NX / 2];
+                    a = make_float2(z.x, 0.f);
+                    b = make_float2(z.y, 0.f);
+                    nyq_rows[frame * ny + 2 * pair] = zn.x;
+                    nyq_rows[frame * ny + 2 * pair + 1] = zn.y;
+                }
+                const size_t o = spec_index(frame, nt, ny, ct_w, 2 * pair, k);
+                spec[o] = a;
+                spec[o + ct_w] = b;  // next row of the same tile
+            }
         }
-        const size_t o = spec_index(frame, nt, ny, ct_w, 2 * pair, k);
-        spec[o] = a;
-        spec[o + ct_w] = b;  // next row of the same tile
     }
 }
 
@@ -948,13 +967,14 @@ template <int NX>
 static int launch_r2c(const b4d_plan* pl, const float* in, float2* spec, float* nyq_rows, const RowSrc* srcs, int batch,
                       hipStream_t st) {
     constexpr int SEQ = row_seq(NX);
-    const dim3 grid((pl->ny / 2 + SEQ - 1) / SEQ, batch), block((NX / E16) * SEQ);
+    constexpr int ITER = NX >= 1024 ? B4D_K1_ITER : 1;   // groups of row pairs per workgroup, full frames only
+    const dim3 block((NX / E16) * SEQ);
     if (srcs)
-        hipLaunchKernelGGL((k_row_r2c<NX, SEQ, true>), grid, block, 0, st, in, spec, nyq_rows, pl->tw_x, pl->ny,
-                           pl->ct_w, srcs);
+        hipLaunchKernelGGL((k_row_r2c<NX, SEQ, true>), dim3((pl->ny / 2 + SEQ - 1) / SEQ, batch), block, 0, st, in, spec, nyq_rows,
+                           pl->tw_x, pl->ny, pl->ct_w, srcs);
     else
-        hipLaunchKernelGGL((k_row_r2c<NX, SEQ, false>), grid, block, 0, st, in, spec, nyq_rows, pl->tw_x, pl->ny,
-                           pl->ct_w, srcs);
+        hipLaunchKernelGGL((k_row_r2c<NX, SEQ, false, ITER>), dim3((pl->ny / 2 + SEQ * ITER - 1) / (SEQ * ITER), batch), block, 0, st,
+                           in, spec, nyq_rows, pl->tw_x, pl->ny, pl->ct_w, srcs);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
