@@ -51,6 +51,7 @@ SIGNATURES = {
     "b4d_autocorr2d": (_i, [_vp, _vp, _i, _vp, _u, _vp]),
     "b4d_psd_autocorr2d": (_i, [_vp, _vp, _i, _vp, _f, _vp, _u, _vp]),
     "b4d_psd_autocorr2d_timed": (_i, [_vp, _vp, _i, _vp, _f, _vp, _u, _vp, _vp]),
+    "b4d_plan_tune": (_i, [_vp, _vp, _i, _vp, _f, _vp, _u, _i, _vp, _vp, _vp]),
     "b4d_xcorr2d": (_i, [_vp, _vp, _vp, _i, _vp, _u, _vp]),
     "b4d_phase_correlation": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _d, _vp, _vp, _vp]),
     "b4d_template_match": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
@@ -146,6 +147,18 @@ class Plan:
 
     def workspace_bytes(self) -> int:
         return int(lib().b4d_plan_workspace_bytes(self._h))
+
+    def tune(self, frames, psd=None, autocorr=None, psd_scale: float = 1.0, flags: int = 0, candidates: int = 3):
+        """b4d_plan_tune: keep the fastest of up to `candidates` workspace allocations for THIS call (device tensors
+        `frames` (T, ny, nx) float32 and the output tensors of a normal psd / autocorrelation call).  Returns
+        (ms per pass on the kept workspace, ms per pass on the slowest candidate).  Where a multi-GB buffer lands in device
+        memory is worth 5-10 % of every kernel streaming through it."""
+        best, worst = C.c_float(0.0), C.c_float(0.0)
+        check(lib().b4d_plan_tune(self._h, C.c_void_p(frames.data_ptr()), int(frames.shape[0]),
+                                  C.c_void_p(psd.data_ptr()) if psd is not None else None, float(psd_scale),
+                                  C.c_void_p(autocorr.data_ptr()) if autocorr is not None else None, int(flags), int(candidates),
+                                  C.byref(best), C.byref(worst), stream_ptr()))
+        return float(best.value), float(worst.value)
 
     def close(self):
         if getattr(self, "_h", None):

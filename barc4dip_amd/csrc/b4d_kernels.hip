@@ -212,6 +212,64 @@ int b4d_psd_autocorr2d_timed(b4d_plan* pl, const float* frames, int batch, float
     return psd_autocorr_impl(pl, frames, batch, psd, psd_scale, autocorr, flags, (hipStream_t)stream, kernel_ms);
 }
 
+// Workspace placement (include/b4d.h).  The plan's half-spectrum workspace is exchanged for up to `candidates` - 1 fresh
+// allocations, each timed on the caller's own call; the fastest stays.
+int b4d_plan_tune(b4d_plan* pl, const float* frames, int batch, float* psd, float psd_scale, float* autocorr, unsigned flags,
+                  int candidates, float* best_ms, float* worst_ms, void* stream) {
+    if (!pl) return fail(B4D_EINVAL, "plan is null");
+    B4D_PLAN_LOCK(pl);
+    if (best_ms) *best_ms = 0.f;
+    if (worst_ms) *worst_ms = 0.f;
+    if (pl->general || !pl->spec) return B4D_OK;   // power-of-two plans only: the other engines size their buffers per call
+    if (candidates < 2) return fail(B4D_EINVAL, "candidates must be >= 2");
+    candidates = std::min(candidates, 8);
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float2*> cand{pl->spec};
+    std::vector<float> ms;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    B4D_HIP(hipEventCreate(&e0));
+    B4D_HIP(hipEventCreate(&e1));
+    int rc = B4D_OK;
+    for (int i = 0; i < candidates && rc == B4D_OK; ++i) {
+        if (i > 0) {   // an allocation failure only ends the search
+            float2* q = nullptr;
+            if (hipMalloc((void**)&q, pl->ws_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            cand.push_back(q);
+            pl->spec = q;
+        }
+        float t = 0.f;
+        for (int rep = 0; rep < 3 && rc == B4D_OK; ++rep) {   // first pass untimed
+            if (rep == 1 && hipEventRecord(e0, st) != hipSuccess) rc = fail(B4D_EHIP, "hipEventRecord");
+            if (rc == B4D_OK) rc = psd_autocorr_impl(pl, frames, batch, psd, psd_scale, autocorr, flags, st, nullptr);
+        }
+        if (rc == B4D_OK && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                             hipEventElapsedTime(&t, e0, e1) != hipSuccess))
+            rc = fail(B4D_EHIP, "timing a candidate workspace failed");
+        ms.push_back(0.5f * t);
+    }
+    (void)hipStreamSynchronize(st);
+    size_t best = 0, worst = 0;
+    if (rc == B4D_OK)
+        for (size_t i = 1; i < ms.size(); ++i) {
+            if (ms[i] < ms[best]) best = i;
+            if (ms[i] > ms[worst]) worst = i;
+        }
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (i != best) (void)hipFree(cand[i]);
+    pl->spec = cand[best];
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != B4D_OK) return rc;
+    if (best_ms) *best_ms = ms[best];
+    if (worst_ms) *worst_ms = ms[worst];
+    // the kept workspace holds whatever its own timing passes left: the outputs are those of a normal call only if it ran last
+    if (best + 1 != cand.size()) rc = psd_autocorr_impl(pl, frames, batch, psd, psd_scale, autocorr, flags, st, nullptr);
+    return rc;
+}
+
 int b4d_psd2d(b4d_plan* pl, const float* frames, int batch, float* psd, float scale, void* stream) {
     if (!psd) return fail(B4D_EINVAL, "psd is null");
     return b4d_psd_autocorr2d(pl, frames, batch, psd, scale, nullptr, 0u, stream);

@@ -93,6 +93,18 @@ int b4d_psd_autocorr2d(b4d_plan* plan, const float* frames, int batch, float* ps
 int b4d_psd_autocorr2d_timed(b4d_plan* plan, const float* frames, int batch, float* psd, float psd_scale,
                              float* autocorr, unsigned flags, void* stream, float* kernel_ms);
 
+/* Workspace placement (power-of-two plans; a no-op returning B4D_OK on the others).  Where a multi-GB allocation lands in
+ * device memory decides 5-10 % of the time of every kernel that streams through it -- a property of the allocation that
+ * stays with it until it is freed (same code, same virtual layout, two hipMalloc's of one process).
+ * The plan owns its half-spectrum workspace, so it can measure: up to `candidates` - 1 (at most 7) further workspaces are
+ * allocated one after the other, the caller's own b4d_psd_autocorr2d call is timed with each (two passes after an untimed
+ * one), the fastest stays with the plan and the others are freed.  An allocation failure only ends the search.  Synchronises
+ * `stream`; on return psd / autocorr hold the result of a normal call.  best_ms / worst_ms (optional) receive the time per
+ * pass on the kept and on the slowest candidate.  All candidates are alive until the choice is made: up to
+ * (candidates - 1) x b4d_plan_workspace_bytes of extra device memory for the duration of the call.                         */
+int b4d_plan_tune(b4d_plan* plan, const float* frames, int batch, float* psd, float psd_scale, float* autocorr,
+                  unsigned flags, int candidates, float* best_ms, float* worst_ms, void* stream);
+
 /* signal/corr.py:169-253 xcorr2d -- fftshift(ifft2(fft2(a) * conj(fft2(b)))), real part,
  * float32, scaled 1/(nx*ny) like ifft2.  B4D_REMOVE_MEAN zeroes the DC bin of the cross
  * spectrum (= both means removed), B4D_NORM_PEAK divides by max|corr|.                   */

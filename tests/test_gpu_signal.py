@@ -149,6 +149,44 @@ def test_stack_equals_frames_and_chunking(gs):
         np.testing.assert_array_equal(a, outs[0][1])
 
 
+def test_plan_tune_keeps_results_and_a_working_plan(gs):
+    """b4d_plan_tune exchanges the plan's workspace for the fastest of several allocations: outputs after the call, and of
+    later calls on the tuned plan, are bit-identical to an untuned plan's; general-length plans take it as a no-op."""
+    import torch
+
+    from barc4dip_amd import _ffi
+    import ctypes as C
+
+    stack = synth.speckle_stack(6, 512, seed0=77)
+    dev = torch.from_numpy(stack).cuda()
+
+    def call(pl, p, a):
+        _ffi.check(_ffi.lib().b4d_psd_autocorr2d(pl.handle, C.c_void_p(dev.data_ptr()), 6, C.c_void_p(p.data_ptr()), 0.5,
+                                                 C.c_void_p(a.data_ptr()), 3, _ffi.stream_ptr()))
+        torch.cuda.synchronize()
+
+    ref_p, ref_a = torch.empty_like(dev), torch.empty_like(dev)
+    pl0 = _ffi.Plan(512, 512, 4)
+    call(pl0, ref_p, ref_a)
+    pl0.close()
+    pl = _ffi.Plan(512, 512, 4)
+    p, a = torch.full_like(dev, -1.0), torch.full_like(dev, -1.0)
+    best, worst = pl.tune(dev, p, a, psd_scale=0.5, flags=3, candidates=4)
+    assert 0.0 < best <= worst
+    assert torch.equal(p, ref_p) and torch.equal(a, ref_a)
+    p.fill_(-1.0)
+    a.fill_(-1.0)
+    call(pl, p, a)
+    assert torch.equal(p, ref_p) and torch.equal(a, ref_a)
+    with pytest.raises(_ffi.B4DError):
+        pl.tune(dev, p, a, candidates=1)
+    pl.close()
+    g = _ffi.Plan(300, 300, 2)   # DFT-matrix plan: nothing to tune, nothing reported
+    d3 = torch.zeros((2, 300, 300), dtype=torch.float32, device="cuda")
+    assert g.tune(d3, torch.empty_like(d3), None) == (0.0, 0.0)
+    g.close()
+
+
 def test_full_size_properties(gs):
     """Size-independent properties at the benchmark size (2048^2, 8-frame stack)."""
     import torch
