@@ -358,7 +358,10 @@ def main():
             stack = torch.cat([stack, _synth.speckle_stack_device(1024 - T, N, seed0=777 + 100000 * rank)]) if T < 1024 else stack
         except Exception:      # not enough free HBM for 16 GiB: keep the 256-frame shard
             pass
-        c4 = secondary_cfg4(torch, dist, stack, world, rank, cpu)
+        try:
+            c4 = secondary_cfg4(torch, dist, stack, world, rank, cpu)
+        except Exception as e:      # e.g. RCCL failing to come up on every rank alike: the headline line is still printed
+            c4 = {"error": repr(e)}
         if rank == 0:
             secondary["cfg4"] = c4
         if world == 1:
