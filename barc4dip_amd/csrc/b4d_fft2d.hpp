@@ -33,6 +33,14 @@
 #include "b4d_common.hpp"
 #include "b4d_fft.hpp"
 
+// Translation units that build a kernel with their own compiler flags (b4d_passes.hpp) define B4D_UNIT_TAG before including
+// this header: the tag is a template argument of the kernels they launch, so that their instantiations are symbols of their
+// own -- two units instantiating the SAME kernel name share one host-side stub, and which unit's device code a launch then
+// runs is decided by registration order, not by the caller.
+#ifndef B4D_UNIT_TAG
+#define B4D_UNIT_TAG 0
+#endif
+
 namespace b4d {
 
 constexpr int E16 = 16;
@@ -266,7 +274,7 @@ __device__ __forceinline__ void store_cols(float2* __restrict__ rowp, const floa
 }
 
 // grid (nt, batch), block ColCfg<NY>::THREADS.
-template <int NY, int MODE, int SPLIT = 1>
+template <int NY, int MODE, int SPLIT = 1, int UNIT = 0>
 __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLIT>::WAVES_PER_EU)) k_col(ColArgs p) {
     using Cfg = ColCfg<NY, SPLIT>;
     using G = typename Cfg::G;
@@ -620,7 +628,7 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
 //   C2R_OUT   shifted real output, scaled (flags & NORM_PEAK: by 1/peak[frame], zero lag forced to 1)
 //   C2R_PEAK  only the zero-lag value of each frame -> peak[frame]
 //   C2R_MAG   |value| * scale (signal/tracking.py:283-285) + per-workgroup arg-max partials
-template <int NX, int SEQ, int MODE>
+template <int NX, int SEQ, int MODE, int UNIT = 0>
 __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
     using G = RowGeom<NX>;
     constexpr int T = G::T, E = E16;
@@ -928,11 +936,11 @@ static int launch_col(const ColArgs& a, int ntiles, int batch, hipStream_t st) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col<NY, MODE, SPLIT>),
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col<NY, MODE, SPLIT, B4D_UNIT_TAG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     });
     B4D_HIP(attr_err);
-    hipLaunchKernelGGL((k_col<NY, MODE, SPLIT>), dim3(ntiles * SPLIT, batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_col<NY, MODE, SPLIT, B4D_UNIT_TAG>), dim3(ntiles * SPLIT, batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
@@ -1003,17 +1011,17 @@ static int launch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, int mo
         // with a.gate (full maps for the few frames that need them) the workgroups of every other frame leave at once; a loop
         // over row blocks inside the kernel instead of the full grid was tried: the compiler hoists the transform's twiddle
         // and address set out of it (92 -> 236 VGPRs, half the occupancy of the main pass that shares the instantiation)
-        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_MAG>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_MAG, B4D_UNIT_TAG>), grid, block, 0, st, a);
         B4D_HIP(hipGetLastError());
         return B4D_OK;
     }
     if (mode == C2R_ROWS) {   // three row pairs around each frame's peak (a.nblk partials per frame)
-        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_ROWS>), dim3((3 + SEQ - 1) / SEQ, batch), block, 0, st, a);
+        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_ROWS, B4D_UNIT_TAG>), dim3((3 + SEQ - 1) / SEQ, batch), block, 0, st, a);
         B4D_HIP(hipGetLastError());
         return B4D_OK;
     }
     if (a.flags & B4D_NORM_PEAK) {
-        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_PEAK>), dim3(1, batch), block, 0, st, a);
+        hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_PEAK, B4D_UNIT_TAG>), dim3(1, batch), block, 0, st, a);
         B4D_HIP(hipGetLastError());
         if (ev) {
             hipEvent_t e;
@@ -1022,7 +1030,7 @@ static int launch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, int mo
             B4D_HIP(hipEventRecord(e, st));
         }
     }
-    hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_OUT>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((k_row_c2r<NX, SEQ, C2R_OUT, B4D_UNIT_TAG>), grid, block, 0, st, a);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }

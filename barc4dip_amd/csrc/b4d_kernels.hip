@@ -1,6 +1,6 @@
 // b4d_kernels.hip -- C ABI (include/b4d.h) of the FFT -> PSD -> autocorrelation hot path
 // (SURVEY.md §8 rows a1-a5).  Kernels live in b4d_fft2d.hpp / b4d_fft.hpp.
-#include "b4d_fft2d.hpp"
+#include "b4d_passes.hpp"
 
 namespace b4d {
 std::string& last_error() {
@@ -150,7 +150,7 @@ static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float
 #ifdef B4D_DIAG
         ca.diag = g_diag;
 #endif
-        if ((rc = dispatch_col<COL_PSD_AC>(pl, ca, nb, st))) break;
+        if ((rc = col_psd_ac_pass(pl, ca, nb, st))) break;
         NyqArgs na{};
         na.rows = pl->nyq_rows;
         na.g_out = pl->gnyq;
@@ -170,7 +170,7 @@ static int psd_autocorr_impl(b4d_plan* pl, const float* frames, int batch, float
             ra.ct_w = pl->ct_w;
             ra.flags = flags;
             ra.half = 1;
-            if ((rc = dispatch_c2r(pl, ra, nb, st, C2R_OUT, kernel_ms ? &ev : nullptr))) break;
+            if ((rc = row_out_pass(pl, ra, nb, st, kernel_ms ? &ev : nullptr))) break;
         }
         if ((rc = mark())) break;
     }

@@ -29,7 +29,7 @@ def main():
     alg = {"k_col": (4 * n * n + 4 * n * n + 8 * (n // 2 + 2) * (n // 2)) * frames, "k_row_r2c": 8 * n * n * frames,
            "k_row_c2r": (4 * (n // 2 + 2) * n + 4 * n * n) * frames}
     res = {}
-    for tag, match in (("k_col", "k_col<2048, 0"), ("k_row_r2c", "k_row_r2c<2048"), ("k_row_c2r", "k_row_c2r<2048, 2, 0>")):
+    for tag, match in (("k_col", "k_col<2048, 0"), ("k_row_r2c", "k_row_r2c<2048"), ("k_row_c2r", "k_row_c2r<2048, 2, 0")):
         f = [v for k, v in fe.items() if match in k]
         w = [v for k, v in wr.items() if match in k]
         if not f or not w:
