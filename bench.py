@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default: the cfg2 stack)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per launch group (0 = library default)")
     ap.add_argument("--cpu-frames", type=int, default=8)
-    ap.add_argument("--tune", type=int, default=3, help="workspace candidates of b4d_plan_tune during warm-up (0 / 1 = off)")
+    ap.add_argument("--tune", type=int, default=6, help="workspace candidates of b4d_plan_tune during warm-up (0 / 1 = off)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / cfg4 / cfg5 block after the timed region")
     args = ap.parse_args()
@@ -319,7 +319,7 @@ def main():
 
     # warm-up, part 1: workspace placement.  Where a multi-GB allocation lands in device memory is worth 5-10 % of every kernel
     # streaming through it (same code, two hipMalloc's of one process, column pass 2.50 against 2.63 ms); the
-    # plan measures this very call on up to three workspace allocations and keeps the fastest (b4d_plan_tune).  Untimed, like
+    # plan measures this very call on up to six workspace allocations (--tune) and keeps the fastest (b4d_plan_tune).  Untimed, like
     # the warm-up steps; the timed region below runs on the plan as it stands afterwards.
     tuned = None
     if args.tune > 1:
