@@ -40,6 +40,17 @@
 #ifndef B4D_UNIT_TAG
 #define B4D_UNIT_TAG 0
 #endif
+// Which launch dispatchers a unit compiles (bit mask).  Every kernel a dispatcher names is instantiated in the including unit, with
+// THAT unit's flags, under a symbol the other units share unless it carries the tag: a unit built with flags of its own therefore
+// compiles only the pass it exists for (b4d_colpass.hip: the column pass, b4d_rowout.hip: the inverse row pass), so that no kernel
+// symbol has two different device codes in the library (`make check-symbols`).
+#define B4D_PASS_R2C 1
+#define B4D_PASS_COL 2
+#define B4D_PASS_NYQ 4
+#define B4D_PASS_C2R 8
+#ifndef B4D_UNIT_PASSES
+#define B4D_UNIT_PASSES (B4D_PASS_R2C | B4D_PASS_COL | B4D_PASS_NYQ | B4D_PASS_C2R)
+#endif
 
 namespace b4d {
 
@@ -926,6 +937,7 @@ static inline int make_twiddles(int n, float2** out) {
         case 4096: return CALL(4096);   \
     }
 
+#if B4D_UNIT_PASSES & B4D_PASS_COL
 #ifndef B4D_COL_SPLIT
 #define B4D_COL_SPLIT 1
 #endif
@@ -952,7 +964,9 @@ static int dispatch_col(const b4d_plan* pl, const ColArgs& a, int batch, hipStre
 #undef B4D_CALL
     return fail(B4D_ESIZE, "unsupported ny");
 }
+#endif  // B4D_PASS_COL
 
+#if B4D_UNIT_PASSES & B4D_PASS_NYQ
 template <int NY, int MODE>
 static int launch_nyq(const NyqArgs& a, hipStream_t st) {
     constexpr int SEQ = row_seq(NY);
@@ -970,7 +984,9 @@ static int dispatch_nyq(const b4d_plan* pl, NyqArgs a, int items, hipStream_t st
 #undef B4D_CALL
     return fail(B4D_ESIZE, "unsupported ny");
 }
+#endif  // B4D_PASS_NYQ
 
+#if B4D_UNIT_PASSES & B4D_PASS_R2C
 template <int NX>
 static int launch_r2c(const b4d_plan* pl, const float* in, float2* spec, float* nyq_rows, const RowSrc* srcs, int batch,
                       hipStream_t st) {
@@ -997,7 +1013,9 @@ static int dispatch_r2c(const b4d_plan* pl, const float* in, int batch, hipStrea
 #undef B4D_CALL
     return fail(B4D_ESIZE, "unsupported nx");
 }
+#endif  // B4D_PASS_R2C
 
+#if B4D_UNIT_PASSES & B4D_PASS_C2R
 // mode: C2R_OUT (with a C2R_PEAK pre-pass when NORM_PEAK) or C2R_MAG.  ev: optional event sink (timed runs).
 template <int NX>
 static int launch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, int mode, hipStream_t st,
@@ -1041,3 +1059,4 @@ static int dispatch_c2r(const b4d_plan* pl, const RowOutArgs& a, int batch, hipS
 #undef B4D_CALL
     return fail(B4D_ESIZE, "unsupported nx");
 }
+#endif  // B4D_PASS_C2R

@@ -40,7 +40,7 @@ N = 2048
 FRAMES_PER_GPU = 256
 BENCH_CHUNK = 256              # frames per launch group of the plan the bench creates (see main())
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILE = "profiles/r02_pmc_col.json"
+PMC_FILE = "profiles/r03_pmc_col.json"
 
 
 def baseline_metric() -> str:
@@ -96,6 +96,19 @@ def cpu_baseline(n: int, frames: int):
     return out
 
 
+HBM_COPY_GBS = 6290.0          # MI355X_MICROARCH.md: what a float4 copy kernel reaches (the practical ceiling of a stream)
+
+
+def fractions(model_bytes: float, moved_bytes: float, units_per_s: float) -> dict:
+    """Three readings of one rate.  `model` prices SURVEY.md §8(d)'s pass-by-pass byte model (what BASELINE.md quotes; fusion
+    can push it past the copy ceiling, so it is NOT a distance to the roof); `moved` prices the bytes the kernels of THIS
+    implementation have to move (DESIGN.md's accounting, cross-checked by the FETCH_SIZE / WRITE_SIZE counters under profiles/);
+    `frac_of_copy` is `moved` against the 6.29 TB/s a plain copy reaches on this part."""
+    gm, gv = model_bytes * units_per_s / 1e9, moved_bytes * units_per_s / 1e9
+    return {"model_bytes": int(model_bytes), "moved_bytes": int(moved_bytes), "model_GBps": gm, "moved_GBps": gv,
+            "frac_model": gm / HBM_PEAK_GBS, "frac_moved": gv / HBM_PEAK_GBS, "frac_of_copy": gv / HBM_COPY_GBS}
+
+
 # ---------------------------------------------------------------------------------------------- secondary configs
 def _best_of(fn, sync, reps):
     fn()
@@ -107,6 +120,38 @@ def _best_of(fn, sync, reps):
         sync()
         best = min(best, time.perf_counter() - t0)
     return best
+
+
+def secondary_fft2d(torch, stack, cpu: bool):
+    """SURVEY.md §8 row a1 (signal/fft.py:198-237): fftshift(fft2(frame)) of every frame of a resident stack -> complex64 full
+    spectra, through the public fft2d_stack.  Model: 4 B in + 8 B out per pixel ("if fft2d's complex output is also
+    materialised add 8 N^2").  Moved: the two passes of the implementation (real columns -> half spectrum, rows -> full spectrum)."""
+    from barc4dip_amd.signal.fft import fft2d_stack
+
+    T, n = min(int(stack.shape[0]), 128), int(stack.shape[-1])
+    sub = stack[:T]
+    res = {}
+
+    def run():
+        res["out"] = fft2d_stack(sub, return_tensors=True)
+
+    best = _best_of(run, torch.cuda.synchronize, 3)
+    model = 12 * n * n
+    moved = 4 * n * n + 8 * n * (n // 2 + 1) + 8 * n * (n // 2 + 1) + 8 * n * n
+    line = {"workload": f"fft2d (row a1): {T} resident frames of {n}x{n} float32 -> shifted complex64 spectra",
+            "frames_per_s": T / best, **fractions(model, moved, T / best)}
+    if cpu:
+        from oracle import signal_np as S
+
+        t0 = time.perf_counter()
+        ref = S.fft2d(sub[0].cpu().numpy().astype(np.float64))[0]
+        dt = time.perf_counter() - t0
+        got = res["out"][0].cpu().numpy()
+        line.update({"max_err_vs_oracle_over_peak": float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))),
+                     "cpu_port_frames_per_s": 1.0 / dt, "cpu_sample": "1 frame, float64 oracle, 1 core"})
+    del res
+    torch.cuda.empty_cache()
+    return line
 
 
 def secondary_cfg3(torch, cpu: bool):
@@ -136,11 +181,17 @@ def secondary_cfg3(torch, cpu: bool):
     npairs = len(pair_img)
     truth = bool(np.all(np.median(np.rint(out[:9 * T, 0]).reshape(T, 9), axis=1) == sh[:, 0]) and
                  np.all(np.median(np.rint(out[:9 * T, 1]).reshape(T, 9), axis=1) == sh[:, 1]))
-    nh = n // 2 + 1
-    bytes_pair = 12 * n * n + 56 * n * nh
+    nh, hh = n // 2 + 1, n // 2
+    model = 12 * n * n + 56 * n * nh
+    # bytes this implementation moves per pair (profiles/*pmc_cfg3*): every image spectrum is built once and shared
+    # by its 18 pairs (row pass 4n^2 + 4n^2, column pass in place 4n^2 + 4n^2); a template spectrum is built once per (frame, ROI)
+    # from its `side` non-zero rows (row pass side^2*4 in, side*n/2*8 out; column pass reads those rows, writes the whole half
+    # spectrum) and serves the "abs" pairs of all frames or one "inc" pair; per pair the cross-power column pass reads two half
+    # spectra and writes one, the inverse row pass reads it and writes no map (arg-max, median bin and 3 rows only).
+    ntpl = len(tpl_frame)
+    moved = (T * 16 * n * n + ntpl * (4 * side * side + 2 * 8 * side * hh + 8 * n * hh)) / npairs + 3 * 8 * n * hh + 8 * n * hh
     line = {"workload": f"cfg3: phase-correlation tracking, {T} resident frames of {n}x{n}, 3x3 ROI grid abs + inc ({npairs} pairs)",
-            "pairs_per_s": npairs / best, "frames_per_s": T / best, "bytes_per_pair": bytes_pair,
-            "achieved_GBps": bytes_pair * npairs / best / 1e9, "frac": bytes_pair * npairs / best / 1e9 / HBM_PEAK_GBS,
+            "pairs_per_s": npairs / best, "frames_per_s": T / best, **fractions(model, moved, npairs / best),
             "ground_truth_recovered": truth}
     if cpu:
         from oracle import signal_np as S
@@ -177,10 +228,13 @@ def secondary_cfg5(torch, cpu: bool):
 
     best = _best_of(run, torch.cuda.synchronize, 3)
     m, mh = n + 8, (n + 8) // 2 + 1
-    bytes_frame = 12 * m * m + 48 * m * mh + 4 * n * n
+    model = 12 * m * m + 48 * m * mh + 4 * n * n
+    # moved (counters under profiles/): rows forward 4 n^2 in + 8 m mh out, columns 8 m mh in + 8 m mh (complex
+    # filter) + 8 m mh out, rows inverse 8 m mh in + 4 n^2 out = 67 + 67, 67 + 67 + 67, 67 + 67 MB at 4096^2 (no padded copy,
+    # no transposes, no max pass)
+    moved = 4 * n * n + 8 * m * mh + 3 * 8 * m * mh + 8 * m * mh + 4 * n * n
     line = {"workload": f"cfg5: Wiener deconvolution, {T} resident frames of {n}x{n}, sigma {sigma} (padded {m}x{m} = 8*27*19)",
-            "frames_per_s": T / best, "bytes_per_frame": bytes_frame, "achieved_GBps": bytes_frame * T / best / 1e9,
-            "frac": bytes_frame * T / best / 1e9 / HBM_PEAK_GBS}
+            "frames_per_s": T / best, **fractions(model, moved, T / best)}
     if cpu:
         from oracle import wiener_np as W
 
@@ -230,8 +284,7 @@ def secondary_cfg4(torch, dist, stack, world: int, rank: int, cpu: bool):
     bytes_frame = 4 * H * W
     line = {"workload": f"cfg4: temporal mean/var/contrast, {T} frames of {H}x{W} per GPU x {world} GPU(s), "
                         + ("one RCCL all-reduce of 2*H*W+2 float64" if world > 1 else "no collective at N = 1"),
-            "frames_per_s": T * world / best, "bytes_per_frame": bytes_frame,
-            "achieved_GBps_per_gpu": bytes_frame * T / best / 1e9, "frac": bytes_frame * T / best / 1e9 / HBM_PEAK_GBS,
+            "frames_per_s": T * world / best, "per_gpu": fractions(bytes_frame, bytes_frame, T / best),
             "allreduce_ms": tm.get("allreduce_ms"), "allreduce_payload_bytes": 8 * (2 * H * W + 2) if world > 1 else 0}
     # correctness on a small stack that every rank can generate: N-rank sharded result == single-rank result, and both
     # against the float64 NumPy expressions (oracle/temporal_np.py)
@@ -261,7 +314,7 @@ def secondary_cfg4(torch, dist, stack, world: int, rank: int, cpu: bool):
     return line
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -269,30 +322,117 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default: the cfg2 stack)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per launch group (0 = library default)")
     ap.add_argument("--cpu-frames", type=int, default=8)
-    ap.add_argument("--tune", type=int, default=6, help="workspace candidates of b4d_plan_tune during warm-up (0 / 1 = off)")
+    ap.add_argument("--tune", type=int, default=0, help="workspace candidates of b4d_plan_tune during warm-up (0 / 1 = off, the default: "
+                                                        "the library places its workspaces itself)")
+    ap.add_argument("--tune-compare", type=int, default=6, help="after the timed region (N = 1): candidates of a b4d_plan_tune "
+                                                                "comparison run reported beside `value` (0 / 1 = off)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / cfg4 / cfg5 block after the timed region")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fft2d / cfg3 / cfg4 / cfg5 block after the timed region")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="rendezvous only: every rank joins the host-side (gloo) group, rank 0 prints what it saw; no GPU call")
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
+
+def free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: THIS process (which has not imported torch.cuda and never touches the
+    GPU) starts N children of the same command line, one rank per GPU, with the torch.distributed environment of a one-node
+    job on the loopback interface, relays rank 0's stdout (the JSON line) and returns non-zero if any rank did.  No exec, no
+    restart of a process that has initialised the GPU."""
+    import subprocess
+    import tempfile
+
+    port = free_port()
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), B4D_BENCH_SPAWNED="1")
+            env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        codes = [None] * n
+        while any(c is None for c in codes):      # a rank that dies takes the job down (the others would wait in a collective)
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+            if any(c not in (None, 0) for c in codes):
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.terminate()
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        try:
+                            codes[r] = p.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                            codes[r] = p.wait()
+                break
+            time.sleep(0.05)
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode("utf-8", "replace"))
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, argv))      # nothing below runs in the parent: it never sees the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # modulo: lets a 1-GPU box rehearse N > 1
-    if world > 1:
+    if world != args.gpus:      # a job of another size than the one asked for must fail, not degrade to what is there
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as n_gpus={args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+
+    backend = os.environ.get("B4D_BENCH_BACKEND", "cpu:gloo,cuda:nccl")
+    rehearsal = "nccl" not in backend        # B4D_BENCH_BACKEND=gloo: N ranks on fewer GPUs (RCCL refuses duplicate devices);
+    if world > 1:                             # never set by the driver
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one node by contract: keep every rendezvous on the loopback interface (the container hostname may not resolve)
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    if args.spawn_check:
+        if os.environ.get("B4D_BENCH_TEST_FAIL_RANK") == str(rank):      # tests/test_bench_spawn.py: a rank that dies before the rendezvous
+            sys.exit(7)
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+        seen = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"spawn_check": True, "n_gpus": world, "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                              "rank_sum": float(seen.item()), "launcher": "bench.py" if os.environ.get("B4D_BENCH_SPAWNED") else "external"}),
+                  flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ndev = torch.cuda.device_count()
+    if ndev < world and not rehearsal:
+        raise SystemExit(f"--gpus {world} but only {ndev} device(s) visible (B4D_BENCH_BACKEND=gloo rehearses N ranks on fewer GPUs)")
+    torch.cuda.set_device(local_rank % max(1, ndev))
+    if world > 1:
         # one process per GPU; RCCL ("nccl") carries device collectives (the cfg4 all-reduce; the cfg2 data path has none:
         # frames are sharded, nothing is exchanged), gloo carries the host-side barrier and the max-over-ranks of the timing
-        # B4D_BENCH_BACKEND=gloo: rehearsal of the N > 1 logic with several ranks on ONE GPU (RCCL refuses duplicate devices);
-        # never set by the driver
-        dist.init_process_group(backend=os.environ.get("B4D_BENCH_BACKEND", "cpu:gloo,cuda:nccl"))
+        dist.init_process_group(backend=backend)
 
     from barc4dip_amd import _ffi, synth
 
@@ -317,10 +457,8 @@ def main():
             dist.all_reduce(torch.zeros(1, dtype=torch.float64))
         torch.cuda.synchronize()
 
-    # warm-up, part 1: workspace placement.  Where a multi-GB allocation lands in device memory is worth 5-10 % of every kernel
-    # streaming through it (same code, two hipMalloc's of one process, column pass 2.50 against 2.63 ms); the
-    # plan measures this very call on up to six workspace allocations (--tune) and keeps the fastest (b4d_plan_tune).  Untimed, like
-    # the warm-up steps; the timed region below runs on the plan as it stands afterwards.
+    # `value` is measured on the plan as the library hands it out (no bench-only tuning: --tune 0 is the default).  --tune K > 1
+    # runs b4d_plan_tune BEFORE the warm-up instead (K workspace candidates, fastest kept: DESIGN.md §8.6) -- an experiment knob.
     tuned = None
     if args.tune > 1:
         tuned = plan.tune(stack, psd, ac, psd_scale=1.0 / (N * N), flags=flags, candidates=args.tune)
@@ -342,25 +480,62 @@ def main():
     # sanity on the product of the timed region (not a parity test): peak == 1 at the centre of every frame
     centre = ac[:, N // 2, N // 2]
     ok = bool(torch.all(centre == 1.0).item()) and bool(torch.isfinite(psd[0]).all().item())
+
+    # after the timed region, N = 1 only: the same K steps once more on the workspace b4d_plan_tune keeps out of --tune-compare
+    # candidates -- reported beside `value` so that the placement lottery is visible in the line, never as `value`
+    tune_cmp = None
+    if world == 1 and args.tune <= 1 and args.tune_compare > 1:
+        try:
+            tc = plan.tune(stack, psd, ac, psd_scale=1.0 / (N * N), flags=flags, candidates=args.tune_compare)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                _ffi.check(lib.b4d_psd_autocorr2d(*call))
+            torch.cuda.synchronize()
+            dtt = time.perf_counter() - t1
+            tune_cmp = {"value_with_plan_tune": T * args.steps / dtt, "candidates": args.tune_compare, "kept_ms_per_pass": tc[0],
+                        "slowest_ms_per_pass": tc[1], "note": "same K steps after b4d_plan_tune picked the fastest of the candidate "
+                                                              "workspaces; measured after the timed region, not `value`"}
+        except Exception as e:
+            tune_cmp = {"error": repr(e)}
     plan.close()
     del psd, ac, plan
     torch.cuda.empty_cache()
 
+    def all_ranks_ok(flag: bool) -> bool:
+        """A collective phase runs only if EVERY rank is able to enter it (an OOM on one rank must not leave the others waiting)."""
+        if world == 1:
+            return flag
+        t = torch.tensor([0.0 if flag else 1.0], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item()) == 0.0
+
     secondary = None
+    frames_c4 = T
     if not args.no_secondary:
         cpu = not args.no_cpu
-        secondary = {"note": "measured after the timed region of the headline; never part of `value`; HBM roof 8 TB/s; "
-                             "byte models: SURVEY.md §8(d)"}
+        secondary = {"note": "measured after the timed region of the headline; never part of `value`; HBM roof 8 TB/s, copy ceiling "
+                             "6.29 TB/s; frac_model prices SURVEY.md §8(d)'s byte models, frac_moved the bytes this implementation moves"}
+        if world == 1:
+            try:
+                secondary["fft2d"] = secondary_fft2d(torch, stack, cpu)
+            except Exception as e:
+                secondary["fft2d"] = {"error": repr(e)}
         # cfg4's per-GPU shard is 1024 frames: extend the 256-frame cfg2 stack (the generator is deterministic per seed)
         from barc4dip_amd import synth as _synth
 
+        big = None
         try:
-            stack = torch.cat([stack, _synth.speckle_stack_device(1024 - T, N, seed0=777 + 100000 * rank)]) if T < 1024 else stack
-        except Exception:      # not enough free HBM for 16 GiB: keep the 256-frame shard
-            pass
+            big = torch.cat([stack, _synth.speckle_stack_device(1024 - T, N, seed0=777 + 100000 * rank)]) if T < 1024 else stack
+        except Exception:      # not enough free HBM for 16 GiB on this rank
+            big = None
+        if all_ranks_ok(big is not None):      # every rank has the 1024-frame shard, or every rank keeps the 256-frame one
+            stack = big
+        del big
+        frames_c4 = int(stack.shape[0])
         try:
             c4 = secondary_cfg4(torch, dist, stack, world, rank, cpu)
-        except Exception as e:      # e.g. RCCL failing to come up on every rank alike: the headline line is still printed
+        except Exception as e:      # a rank-local failure is reported; the collective inside has its own agreement step
             c4 = {"error": repr(e)}
         if rank == 0:
             secondary["cfg4"] = c4
@@ -373,7 +548,8 @@ def main():
                 except Exception as e:      # a secondary leg never takes the headline line down with it
                     secondary[name] = {"error": repr(e)}
         else:
-            secondary["cfg3"] = secondary["cfg5"] = "measured at --gpus 1 only (frames are sharded, no collective: N ranks run N copies)"
+            secondary["fft2d"] = secondary["cfg3"] = secondary["cfg5"] = \
+                "measured at --gpus 1 only (frames are sharded, no collective: N ranks run N copies)"
 
     if rank == 0:
         B = algorithmic_bytes(N)
@@ -416,12 +592,25 @@ def main():
                          "avg_launch_ms": col_ms,
                          "kernel_ms_per_step": {"row_r2c": kms[0] / args.steps, "col": kms[1] / args.steps,
                                                 "peak": kms[2] / args.steps, "row_c2r": kms[3] / args.steps}},
-            "pipeline_roofline": {"bytes_per_frame": B["pipe"], "achieved": B["pipe"] * fps / world / 1e9,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
-                                  "frac": B["pipe"] * fps / world / 1e9 / HBM_PEAK_GBS,
-                                  "note": "SURVEY.md §8(d): B_pipe = 12N^2 + 40 N (N/2+1) per frame"},
+            "pipeline_roofline": {**fractions(B["pipe"], B["r2c"] + B["col"] + B["c2r"], fps / world),
+                                  "peak": HBM_PEAK_GBS, "copy_ceiling": HBM_COPY_GBS, "unit": "GB/s per GPU",
+                                  "note": "model = SURVEY.md §8(d) B_pipe = 12N^2 + 40 N (N/2+1) per frame (BASELINE.md's figure; the "
+                                          "north-star bar is frac_model >= 0.30); moved = what the three kernels of this implementation "
+                                          "move (8 + 10 + 6) N^2: the fused column pass removed one round trip of the spectrum, so "
+                                          "frac_model over-states the distance covered to the roof -- read frac_moved / frac_of_copy for that"},
+            "distributed": {"world_size": dist.get_world_size() if world > 1 else 1,
+                            "launcher": "bench.py (self-spawned ranks)" if os.environ.get("B4D_BENCH_SPAWNED") else
+                                        ("torch.distributed.run / external" if world > 1 else "single process"),
+                            "host_backend": (dist.get_backend() if world > 1 else None),
+                            "device_collective_backend": (("nccl (RCCL)" if not rehearsal else "gloo (rehearsal: ranks share GPUs)")
+                                                          if world > 1 else None),
+                            "devices_visible": ndev,
+                            "data_path_collectives": "cfg2: none (frames sharded); cfg4: ONE all-reduce of [count, sum x, sum x^2] "
+                                                     "(secondary.cfg4.allreduce_ms)"},
             "outputs_ok": ok,
         }
+        if tune_cmp is not None:
+            line["plan_tune_comparison"] = tune_cmp
         if secondary is not None:
             line["secondary"] = secondary
         if not args.no_cpu and world == 1:     # the CPU leg is timed at N = 1 only (it would idle the other ranks)
