@@ -400,6 +400,15 @@ def main(argv=None):
     if world != args.gpus:      # a job of another size than the one asked for must fail, not degrade to what is there
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as n_gpus={args.gpus}")
 
+    # ONE JSON line on stdout: libraries underneath (gloo's "[Gloo] Rank 0 is connected to ..." lines, RCCL banners) write to file
+    # descriptor 1 from C++, so everything but the line itself is sent to stderr from here on
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj) -> None:
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import torch
     import torch.distributed as dist
 
@@ -419,9 +428,8 @@ def main(argv=None):
         if world > 1:
             dist.all_reduce(seen)
         if rank == 0:
-            print(json.dumps({"spawn_check": True, "n_gpus": world, "dist_world_size": dist.get_world_size() if world > 1 else 1,
-                              "rank_sum": float(seen.item()), "launcher": "bench.py" if os.environ.get("B4D_BENCH_SPAWNED") else "external"}),
-                  flush=True)
+            emit({"spawn_check": True, "n_gpus": world, "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                  "rank_sum": float(seen.item()), "launcher": "bench.py" if os.environ.get("B4D_BENCH_SPAWNED") else "external"})
         if world > 1:
             dist.destroy_process_group()
         return
@@ -615,7 +623,7 @@ def main(argv=None):
             line["secondary"] = secondary
         if not args.no_cpu and world == 1:     # the CPU leg is timed at N = 1 only (it would idle the other ranks)
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_frames)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.all_reduce(torch.zeros(1, dtype=torch.float64))
         dist.destroy_process_group()

@@ -18,7 +18,8 @@ def _run(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER
 def test_plain_invocation_spawns_n_ranks():
     r = _run(["--gpus", "3", "--spawn-check"])
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout     # ONE JSON line: gloo's connection banners go to stderr
+    line = json.loads(r.stdout)
     assert line["n_gpus"] == 3 and line["dist_world_size"] == 3
     assert line["rank_sum"] == 6.0                      # every rank took part in the collective: 1 + 2 + 3
     assert line["launcher"] == "bench.py"
