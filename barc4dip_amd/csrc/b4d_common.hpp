@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 
@@ -22,6 +23,10 @@ int get_scratch(size_t bytes, void** out, hipStream_t stream);
 // different buffers
 std::recursive_mutex& scratch_mutex();
 #define B4D_SCRATCH_LOCK() std::lock_guard<std::recursive_mutex> b4d_scratch_lk__(::b4d::scratch_mutex())
+
+// b4d_set_option switches (defined next to it, b4d_kernels.hip): routes only, never results; read once per entry-point call
+extern std::atomic<int> g_opt_track_predict;   // "track_predict_bin" 0 / 1 / 2
+extern std::atomic<int> g_opt_exp;             // "exp": development A/B switch (kernel variants under test; 0 = shipped)
 
 #define B4D_HIP(call)                                                                      \
     do {                                                                                   \

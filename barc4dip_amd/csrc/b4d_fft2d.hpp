@@ -182,12 +182,11 @@ k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, float* __rest
 }
 
 // ------------------------------------------------------------------------------------ K2
-enum ColMode { COL_PSD_AC = 0, COL_SPECTRUM = 1, COL_FORWARD = 2 };
+enum ColMode { COL_PSD_AC = 0, COL_FORWARD = 2 };   // (1 was the round-2 full-spectrum store: b4d_spectrum.hip replaced it)
 
 struct ColArgs {
     float2* spec;     // tile-major half spectra, in/out
     float* psd;       // (batch, ny, nx) or null
-    float2* full;     // (batch, ny, nx) complex, COL_SPECTRUM only
     const float2* tw;
     const float2* tw_inv;  // the SAME table through a second, formally unrelated pointer: keeps the compiler from
                            // holding the forward pass's 30 twiddles in registers (or scratch) for the inverse pass
@@ -363,23 +362,6 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
         return;
     }
 
-    if (MODE == COL_SPECTRUM) {  // full shifted complex spectrum: direct half + conjugate mirror
-        float2* out = p.full + frame * (size_t)NY * nx;
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const int ky = u + T * j;
-            const unsigned rd = (unsigned)((ky + NY / 2) & (NY - 1)) * nx, rm = (unsigned)((NY / 2 - ky) & (NY - 1)) * nx;
-            float2 c[NC];
-#pragma unroll
-            for (int k = 0; k < NC; ++k) c[k] = v[k][j];
-            store_cols<NC>(out + rd + nx / 2 + kx0, c);
-#pragma unroll
-            for (int k = 0; k < NC; ++k)
-                if (kx0 + k >= 1) out[rm + nx / 2 - kx0 - k] = make_float2(c[k].x, -c[k].y);
-        }
-        return;
-    }
-
     // ---- COL_PSD_AC: power spectrum, optional PSD store (direct + Hermitian mirror), inverse transform.
     // Two REAL power columns ride one complex transform (Pa + i Pb), separated afterwards with the
     // Hermitian symmetry in y: half the butterflies and LDS traffic of a column-by-column inverse.
@@ -509,14 +491,13 @@ __global__ void __launch_bounds__((ColCfg<NY, SPLIT>::THREADS), (ColCfg<NY, SPLI
 }
 
 // ------------------------------------------------------------------------------------ Nyquist column
-enum NyqMode { NYQ_PSD_AC = 0, NYQ_SPECTRUM = 1, NYQ_FORWARD = 2, NYQ_PROD = 3, NYQ_PROD_WHITEN = 4 };
+enum NyqMode { NYQ_PSD_AC = 0, NYQ_FORWARD = 2, NYQ_PROD = 3, NYQ_PROD_WHITEN = 4 };
 
 struct NyqArgs {
-    const float* rows;   // (items, NY) real Nyquist bins from K1                      [PSD_AC, SPECTRUM, FORWARD]
+    const float* rows;   // (items, NY) real Nyquist bins from K1                      [PSD_AC, FORWARD]
     float2* f_out;       // (items, NY) complex column spectra                          [FORWARD]
     float* g_out;        // (items, NY) real inverse-column output, consumed by K3      [PSD_AC, PROD]
     float* psd;          // (items, NY, nx) or null: column 0 of the shifted PSD        [PSD_AC]
-    float2* full;        // (items, NY, nx): column 0 of the shifted complex spectrum   [SPECTRUM]
     const float2* fa;    // column spectra of the two operands + per-pair indices       [PROD]
     const float2* fb;
     const int* idx_a;
@@ -569,14 +550,6 @@ __global__ void __launch_bounds__((NY / E16) * SEQ) k_nyq(NyqArgs p) {
         if (live) {
 #pragma unroll
             for (int j = 0; j < E; ++j) p.f_out[it * NY + u + T * j] = v[j];
-        }
-        return;
-    }
-    if (MODE == NYQ_SPECTRUM) {
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < E; ++j)
-                p.full[(it * NY + ((u + T * j + NY / 2) & (NY - 1))) * (size_t)p.nx] = v[j];
         }
         return;
     }

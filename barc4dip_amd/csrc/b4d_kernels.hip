@@ -2,17 +2,40 @@
 // (SURVEY.md §8 rows a1-a5).  Kernels live in b4d_fft2d.hpp / b4d_fft.hpp.
 #include "b4d_passes.hpp"
 
+#include <cstring>
+
 namespace b4d {
 std::string& last_error() {
     static thread_local std::string err;
     return err;
 }
+std::atomic<int> g_opt_track_predict{1};
+std::atomic<int> g_opt_exp{0};
+// b4d_spectrum.hip
+int spectrum_rows_last(const b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st);
 }  // namespace b4d
 
 extern "C" {
 
 const char* b4d_version(void) { return "b4d 0.2.0 (gfx950)" B4D_VERSION_SUFFIX; }
 const char* b4d_last_error(void) { return last_error().c_str(); }
+int b4d_set_option(const char* name, int value) {
+    if (!name) return fail(B4D_EINVAL, "null option name");
+    struct Opt {
+        const char* name;
+        std::atomic<int>* v;
+        int lo, hi;
+    };
+    const Opt opts[] = {{"track_predict_bin", &g_opt_track_predict, 0, 2}, {"exp", &g_opt_exp, 0, 255}};
+    for (const Opt& o : opts)
+        if (!strcmp(name, o.name)) {
+            if (value < o.lo || value > o.hi)
+                return fail(B4D_EINVAL, std::string(name) + " takes " + std::to_string(o.lo) + " .. " + std::to_string(o.hi));
+            o.v->store(value);
+            return B4D_OK;
+        }
+    return fail(B4D_EINVAL, std::string("unknown option: ") + name);
+}
 static bool large_ok(int ny, int nx) {
     return ny >= 2 && nx >= 2 && ny <= 8192 && nx <= 8192 && (size_t)ny * nx <= ((size_t)1 << 26) && pm_supported(ny) && pm_supported(nx);
 }
@@ -287,21 +310,9 @@ int b4d_fft2d(b4d_plan* pl, const float* frames, int batch, float* out_c64, void
     hipStream_t st = (hipStream_t)stream;
     if (pl->general) return general_fft2d(pl, frames, batch, reinterpret_cast<float2*>(out_c64), st);
     const size_t fpix = (size_t)pl->ny * pl->nx;
-    for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
-        const int nb = std::min(pl->chunk, batch - b0);
-        int rc = dispatch_r2c(pl, frames + b0 * fpix, nb, st);
-        if (rc) return rc;
-        ColArgs ca{};
-        ca.spec = pl->spec;
-        ca.full = reinterpret_cast<float2*>(out_c64) + b0 * fpix;
-        ca.tw = pl->tw_y;
-        ca.nx = pl->nx;
-        rc = dispatch_col<COL_SPECTRUM>(pl, ca, nb, st);
-        if (rc) return rc;
-        NyqArgs na{};
-        na.rows = pl->nyq_rows;
-        na.full = ca.full;
-        rc = dispatch_nyq<NYQ_SPECTRUM>(pl, na, nb, st);
+    for (int b0 = 0; b0 < batch; b0 += pl->chunk) {   // columns first, rows last (b4d_spectrum.hip): every store of the full
+        const int nb = std::min(pl->chunk, batch - b0);   // spectrum is a whole line
+        int rc = spectrum_rows_last(pl, frames + b0 * fpix, nb, reinterpret_cast<float2*>(out_c64) + b0 * fpix, st);
         if (rc) return rc;
     }
     return B4D_OK;

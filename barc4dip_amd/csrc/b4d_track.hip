@@ -301,14 +301,15 @@ constexpr int SEL_WORDS = sizeof(SelState) / sizeof(unsigned);
 // is where the median of nearly every pair falls.  k_row_c2r counts the elements below / inside that bin and gathers the
 // bin while it writes the map; pairs whose counts put the median elsewhere take the full three-pass select on the map
 // (k_track_fin).  Exactness never depends on the guess.
-static int g_track_predict = 1;     // b4d_set_option("track_predict_bin", 0 / 1 / 2): off, on, on with a deliberately WRONG bin
-                                    // (every pair then takes the gated full-map pass behind the map-free one: tests run all three)
-static unsigned predicted_median_bin(size_t n) {
-    if (!g_track_predict) return 0u;
+// `mode` = b4d_set_option("track_predict_bin", 0 / 1 / 2), read ONCE per entry-point call (b4d::g_opt_track_predict, an atomic in
+// b4d_kernels.hip): off, on, on with a deliberately WRONG bin (every pair then takes the gated full-map pass behind the
+// map-free one: tests run all three)
+static unsigned predicted_median_bin(size_t n, int mode) {
+    if (!mode) return 0u;
     const float med = (float)(0.6744897501960817 / std::sqrt((double)n));
     unsigned bits;
     memcpy(&bits, &med, sizeof(bits));
-    return 1024u + (bits >> 21) + (g_track_predict == 2 ? 3u : 0u);
+    return 1024u + (bits >> 21) + (mode == 2 ? 3u : 0u);
 }
 
 // grid (ceil(pairs / 64)), block 64: the expectation holds for pair i when the median's rank falls inside the expected bin
@@ -815,6 +816,7 @@ static int wmr_phase_correlation(b4d_plan* pl, const float* images, int nimg, co
                                  const int32_t* tpl_roi, int ntpl, const int32_t* pair_img, const int32_t* pair_tpl, int npairs,
                                  int subpixel, double eps, double* out, int32_t* peak_ij, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, nsrc = nimg + ntpl, hp = (ny + 1) / 2, qpf = wmr_quads_per_frame(ny);
+    const int predict_mode = g_opt_track_predict.load();   // one route per call
     const size_t npix = (size_t)ny * nx, selems = wmr_spectrum_elems(ny, nx);
     const int sc = std::max(1, pl->chunk), pc = std::max(1, std::min(npairs, pl->chunk));
     size_t need = 0;
@@ -871,7 +873,7 @@ static int wmr_phase_correlation(b4d_plan* pl, const float* images, int nimg, co
     for (int p0 = 0; p0 < npairs; p0 += pc) {
         const int np = std::min(pc, npairs - p0);
         if ((rc = wmr_product_inverse(spec, spec, pidx + p0, pidx + npairs + p0, np, ny, nx, pl->tw_y, G, 1, (float)eps, 0u, st))) return rc;
-        const unsigned pred = predicted_median_bin(npix);
+        const unsigned pred = predicted_median_bin(npix, predict_mode);
         B4D_HIP(hipMemsetAsync(msel, 0, sizeof(SelState) * (size_t)pc, st));
         if ((rc = wmr_rows_magnitude(G, np, ny, nx, pl->tw_x, mag, pval, pind, reinterpret_cast<unsigned*>(msel), SEL_WORDS, pred, medws, st)))
             return rc;
@@ -1016,15 +1018,6 @@ int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* 
     return B4D_OK;
 }
 
-int b4d_set_option(const char* name, int value) {
-    if (!name) return fail(B4D_EINVAL, "null option name");
-    if (!strcmp(name, "track_predict_bin")) {
-        g_track_predict = value;
-        return B4D_OK;
-    }
-    return fail(B4D_EINVAL, std::string("unknown option: ") + name);
-}
-
 int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const float* tpl_src, int ntplsrc,
                           const int32_t* tpl_frame, const int32_t* tpl_roi, int ntpl, const int32_t* pair_img,
                           const int32_t* pair_tpl, int npairs, int subpixel, double eps, double* out, int32_t* peak_ij,
@@ -1034,6 +1027,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     if (nimg < 1 || ntplsrc < 1 || ntpl < 1 || npairs < 1) return fail(B4D_EINVAL, "counts must be >= 1");
     B4D_PLAN_LOCK(pl);
     const int ny = pl->ny, nx = pl->nx;
+    const int predict_mode = g_opt_track_predict.load();   // one route per call
     for (int k = 0; k < ntpl; ++k) {
         const int32_t* r = tpl_roi + 4 * k;
         if (tpl_frame[k] < 0 || tpl_frame[k] >= ntplsrc || r[0] < 0 || r[1] > ny || r[0] >= r[1] || r[2] < 0 || r[3] > nx ||
@@ -1127,7 +1121,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         ra.ct_w = pl->ct_w;
         ra.part_val = pval;
         ra.part_idx = pind;
-        const unsigned pred = predicted_median_bin(fpix);
+        const unsigned pred = predicted_median_bin(fpix, predict_mode);
         ra.selw = reinterpret_cast<unsigned*>(msel);
         ra.sel_stride = SEL_WORDS;
         ra.pred_bin = pred;

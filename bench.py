@@ -125,7 +125,8 @@ def _best_of(fn, sync, reps):
 def secondary_fft2d(torch, stack, cpu: bool):
     """SURVEY.md §8 row a1 (signal/fft.py:198-237): fftshift(fft2(frame)) of every frame of a resident stack -> complex64 full
     spectra, through the public fft2d_stack.  Model: 4 B in + 8 B out per pixel ("if fft2d's complex output is also
-    materialised add 8 N^2").  Moved: the two passes of the implementation (real columns -> half spectrum, rows -> full spectrum)."""
+    materialised add 8 N^2").  Moved: the two passes of the implementation (b4d_spectrum.hip: real columns -> half spectrum along y,
+    4 + 4 B per pixel; rows of it -> every output row and its conjugate mirror, 4 + 8 B per pixel)."""
     from barc4dip_amd.signal.fft import fft2d_stack
 
     T, n = min(int(stack.shape[0]), 128), int(stack.shape[-1])
@@ -137,7 +138,7 @@ def secondary_fft2d(torch, stack, cpu: bool):
 
     best = _best_of(run, torch.cuda.synchronize, 3)
     model = 12 * n * n
-    moved = 4 * n * n + 8 * n * (n // 2 + 1) + 8 * n * (n // 2 + 1) + 8 * n * n
+    moved = (4 + 4 + 4 + 8) * n * n
     line = {"workload": f"fft2d (row a1): {T} resident frames of {n}x{n} float32 -> shifted complex64 spectra",
             "frames_per_s": T / best, **fractions(model, moved, T / best)}
     if cpu:

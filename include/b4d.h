@@ -47,7 +47,10 @@ const char* b4d_last_error(void);
  *                        correlation map in the pass that produces it and (power-of-two sizes) does not store the map: the rows
  *                        around the peak are recomputed for the sub-pixel step, pairs whose expectation fails get their full map
  *                        from a second, gated pass; 0 = no expectation: full maps, full select; 2 = a deliberately wrong
- *                        expectation (test hook: every pair takes the gated pass). */
+ *                        expectation (test hook: every pair takes the gated pass).
+ *   "exp"                0 .. 255 (default 0): development switch for A/B runs of kernel variants under test in ONE process
+ *                        (tools/dev_*.py); a shipped library has no reader of it.
+ * Values outside an option's range and unknown names return B4D_EINVAL; the options are atomics, read once per entry-point call. */
 int b4d_set_option(const char* name, int value);
 /* 1 if (ny, nx) has a plan: powers of two in [64, 4096] (radix FFT kernels); any sides <= 512 (DFT-matrix products);
  * sides <= 8192 that split as 2^k * A * B with A + B <= 128 (fused in-LDS mixed radix) or any other side <= 4096

@@ -461,3 +461,32 @@ def test_library_loaded_before_torch_still_sees_the_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "(64, 64) True" in out.stdout, out.stderr[-500:]
+
+
+@pytest.mark.parametrize("shape", [(64, 4096), (4096, 64), (128, 1024), (4096, 512), (2048, 256), (256, 2048), (1024, 1024)])
+def test_fft2d_columns_first_rows_last(gs, shape):
+    """fft2d of real frames at power-of-two sizes (b4d_spectrum.hip: column pass on real columns, row pass writes every output row
+    and its conjugate mirror): both column orders of the intermediate (32- and 16-column tiles, ny = 4096), extreme aspect ratios,
+    a stack longer than the plan's launch group, and the symmetries the packing relies on.  signal/fft.py:198-237."""
+    from barc4dip_amd.signal.fft import fft2d_stack
+    from oracle import signal_np as S
+
+    ny, nx = shape
+    T = 67 if ny * nx <= 1 << 18 else 3      # 67 > the default launch group of 64 frames
+    rng = np.random.default_rng(ny * 7 + nx)
+    st = (rng.poisson(200.0, size=(T, ny, nx)) + rng.normal(size=(T, ny, nx))).astype(np.float32)
+    F = fft2d_stack(st)
+    assert F.shape == (T, ny, nx) and F.dtype == np.complex64
+    for t in (0, T - 1):
+        Fr = S.fft2d(st[t].astype(np.float64))[0]
+        assert nerr(F[t], Fr) < TOL
+        e32 = nerr(S.fft2d(st[t])[0], Fr)
+        assert nerr(F[t], Fr) <= max(4 * e32, 2e-7)
+    # Hermitian symmetry of a real frame's spectrum, exactly as stored: F[-ky, -kx] = conj F[ky, kx] bit for bit (the mirror row
+    # is the SAME value conjugated), the four self-conjugate bins are real
+    G = F[T // 2]
+    M = np.roll(G[::-1, ::-1], (1, 1), axis=(0, 1))
+    inner = (slice(1, None), slice(1, None))
+    np.testing.assert_array_equal(G[inner], np.conj(M)[inner])
+    for (y, x) in ((ny // 2, nx // 2), (0, nx // 2), (ny // 2, 0), (0, 0)):
+        assert G[y, x].imag == 0.0
