@@ -325,8 +325,12 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--tune", type=int, default=0, help="workspace candidates of b4d_plan_tune during warm-up (0 / 1 = off, the default: "
                                                         "the library places its workspaces itself)")
-    ap.add_argument("--tune-compare", type=int, default=6, help="after the timed region (N = 1): candidates of a b4d_plan_tune "
-                                                                "comparison run reported beside `value` (0 / 1 = off)")
+    ap.add_argument("--tune-compare", type=int, default=0, help="after the timed region (N = 1): candidates of a b4d_plan_tune "
+                                                                "comparison run reported beside `value` (0 / 1 = off, the default: "
+                                                                "profiles/r03_placement.txt -- the tuner buys nothing once the GPU is warm)")
+    ap.add_argument("--preheat", type=float, default=0.6,
+                    help="seconds of untimed passes BEFORE the W warm-up steps: the first process on an idle GPU runs the column and "
+                         "inverse row kernels 6-7 %% slower for its first ~0.2 s (profiles/r03_placement.txt)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fft2d / cfg3 / cfg4 / cfg5 block after the timed region")
     ap.add_argument("--spawn-check", action="store_true",
@@ -471,6 +475,16 @@ def main(argv=None):
     tuned = None
     if args.tune > 1:
         tuned = plan.tune(stack, psd, ac, psd_scale=1.0 / (N * N), flags=flags, candidates=args.tune)
+    # device spin-up: a GPU that has been idle (a fresh box: the driver's case) reaches its steady state only after a few hundred
+    # milliseconds of load -- profiles/r03_placement.txt: first process on a box 45.7 k frames/s with W = 5, the same plan and
+    # tensors 47.8 k 100 ms later; processes 2-5 47.8-47.9 k from the start.  Untimed, before the W warm-up steps, disclosed in `config`.
+    preheat_passes = 0
+    t_pre = time.perf_counter()
+    while args.preheat > 0 and time.perf_counter() - t_pre < args.preheat:
+        for _ in range(8):
+            _ffi.check(lib.b4d_psd_autocorr2d(*call))
+        torch.cuda.synchronize()
+        preheat_passes += 8
     for _ in range(args.warmup):
         _ffi.check(lib.b4d_psd_autocorr2d(*call))
     barrier()
@@ -590,6 +604,8 @@ def main(argv=None):
             "config": {"workload": f"cfg2: 2D FFT->PSD->autocorr, {T}-frame {N}x{N} fp32 stack per GPU, "
                                    "PSD + autocorr written per frame",
                        "frames_per_gpu": T, "chunk": chunk, "parallelism": f"frames sharded x{world}, no collective",
+                       "preheat": {"seconds": args.preheat, "passes": preheat_passes,
+                                   "note": "untimed passes before the W warm-up steps (idle-GPU spin-up; the timed region is exactly K steps)"},
                        "plan_tune": (None if tuned is None else
                                      {"candidates": args.tune, "kept_ms_per_pass": tuned[0], "slowest_ms_per_pass": tuned[1],
                                       "note": "b4d_plan_tune during warm-up (rank 0's figures): fastest of the plan's workspace "
