@@ -187,13 +187,30 @@ struct FftGeom {
     static constexpr int LDS_ELEMS = (X1 > X2 ? X1 : X2) > N ? (X1 > X2 ? X1 : X2) : N;  // per transform
 };
 
+// Synchronisation of the lanes that share one exchange buffer.  WAVE: every lane of the transform sits in ONE wavefront (row kernels
+// with T <= 64 lanes per transform, laid out transform-major): the LDS executes a wave's instructions in order, so a write is
+// visible to the reads the same wave issues after it -- no s_barrier, the waves of a workgroup (one or two transforms each) run
+// independently of each other; the fences only pin the compiler's order.
+template <bool WAVE>
+__device__ __forceinline__ void fft_sync() {
+    if (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // Three-stage forward FFT on one or two register sets that share lane geometry.
 // `u` = lane position along the transform (0..T-1); `lds` = this transform group's buffer;
 // LDS element address = logical_address * CI + ci.   NV = number of register sets (1 or 2):
 // with NV == 2 the two sets go through the buffer one after the other.
-template <class G, int NV>
+template <class G, int NV, bool WAVE = false>
 struct Fft3 {
     static constexpr int E = G::E, T = G::T, R1 = G::R1, R2 = G::R2, R3 = G::R3, CI = G::CI;
+    static_assert(!WAVE || (T <= 64 && CI == 1), "wave-local synchronisation needs the whole transform in one wavefront");
+    static __device__ __forceinline__ void sync() { fft_sync<WAVE>(); }
 
     template <int R, int CNT, int STRIDE>
     static __device__ __forceinline__ void butterflies(float2 (&v)[E]) {
@@ -247,7 +264,7 @@ struct Fft3 {
         xchg1_write(v, u, ci, lds);
 #endif
 #ifndef B4D_EXP_NOBAR
-        __syncthreads();
+        sync();
 #endif
 #ifndef B4D_EXP_NOXCHG
         xchg1_read(v, u, ci, lds);
@@ -291,7 +308,7 @@ struct Fft3 {
         xchg2_write(v, u, ci, lds);
 #endif
 #ifndef B4D_EXP_NOBAR
-        __syncthreads();
+        sync();
 #endif
 #ifndef B4D_EXP_NOXCHG
         xchg2_read(v, u, ci, lds);
@@ -321,17 +338,17 @@ struct Fft3 {
         if (NV == 2) {
             __builtin_amdgcn_sched_barrier(0);
             stage1(vb, u, tw);
-            __syncthreads();
+            sync();
             xchg1(vb, u, ci, lds);
             __builtin_amdgcn_sched_barrier(0);
         }
         stage2(va, u, tw);
-        __syncthreads();
+        sync();
         xchg2(va, u, ci, lds);
         if (NV == 2) {
             __builtin_amdgcn_sched_barrier(0);
             stage2(vb, u, tw);
-            __syncthreads();
+            sync();
             xchg2(vb, u, ci, lds);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -355,10 +372,10 @@ struct Fft3 {
             for (int b = 0; b < NS; b += SB) {
 #pragma unroll
                 for (int s = 0; s < SB; ++s) stage1(v[b + s], u, tw);
-                if (b > 0) __syncthreads();
+                if (b > 0) sync();
 #pragma unroll
                 for (int s = 0; s < SB; ++s) xchg1_write(v[b + s], u, ci, lds + s * SET_ELEMS);
-                __syncthreads();
+                sync();
 #pragma unroll
                 for (int s = 0; s < SB; ++s) xchg1_read(v[b + s], u, ci, lds + s * SET_ELEMS);
             }
@@ -366,10 +383,10 @@ struct Fft3 {
             for (int b = 0; b < NS; b += SB) {
 #pragma unroll
                 for (int s = 0; s < SB; ++s) stage2(v[b + s], u, tw);
-                __syncthreads();
+                sync();
 #pragma unroll
                 for (int s = 0; s < SB; ++s) xchg2_write(v[b + s], u, ci, lds + s * SET_ELEMS);
-                __syncthreads();
+                sync();
 #pragma unroll
                 for (int s = 0; s < SB; ++s) xchg2_read(v[b + s], u, ci, lds + s * SET_ELEMS);
             }
@@ -382,14 +399,14 @@ struct Fft3 {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             stage1(v[s], u, tw);
-            if (s > 0) __syncthreads();
+            if (s > 0) sync();
             xchg1(v[s], u, ci, lds);
             if (SERIAL) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             stage2(v[s], u, tw);
-            __syncthreads();
+            sync();
             xchg2(v[s], u, ci, lds);
             if (SERIAL) __builtin_amdgcn_sched_barrier(0);
         }

@@ -107,6 +107,7 @@ k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, float* __rest
           const float2* __restrict__ tw, int ny, int ct_w, const RowSrc* __restrict__ srcs) {
     using G = RowGeom<NX>;
     constexpr int T = G::T, E = E16;
+    constexpr bool WV = T <= 64;   // one transform = (part of) one wavefront: no workgroup barriers (fft_sync)
     static_assert(ITER == 1 || !SRC, "ROI sources run one group per workgroup");
     __shared__ float2 lds_all[SEQ * G::LDS_ELEMS];
     const int seq = threadIdx.x / T, u = threadIdx.x % T;
@@ -153,12 +154,12 @@ k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, float* __rest
         float2(&v)[E] = va[it];
         const int pair = (blockIdx.x * ITER + it) * SEQ + seq;
         const bool live = 2 * pair < ny;
-        if (it > 0) __syncthreads();   // the previous group's Hermitian split has read the buffer
-        Fft3<G, 1>::run(v, v, u, 0, lds, tw);
-        __syncthreads();
+        if (it > 0) fft_sync<WV>();   // the previous group's Hermitian split has read the buffer
+        Fft3<G, 1, WV>::run(v, v, u, 0, lds, tw);
+        fft_sync<WV>();
 #pragma unroll
         for (int j = 0; j < E; ++j) lds[u + T * j] = v[j];
-        __syncthreads();
+        fft_sync<WV>();
         if (live) {
 #pragma unroll
             for (int j = 0; j < E / 2; ++j) {
@@ -513,6 +514,7 @@ template <int NY, int SEQ, int MODE>
 __global__ void __launch_bounds__((NY / E16) * SEQ) k_nyq(NyqArgs p) {
     using G = RowGeom<NY>;
     constexpr int T = G::T, E = E16;
+    constexpr bool WV = T <= 64;
     __shared__ float2 lds_all[SEQ * G::LDS_ELEMS];
     const int seq = threadIdx.x / T, u = threadIdx.x % T;
     const int item = blockIdx.x * SEQ + seq;
@@ -528,7 +530,7 @@ __global__ void __launch_bounds__((NY / E16) * SEQ) k_nyq(NyqArgs p) {
             const float2 c = cross_power<MODE == NYQ_PROD_WHITEN>(p.fa[ia * NY + ky], p.fb[ib * NY + ky], p.eps);
             v[j] = make_float2(c.y, c.x);  // swapped: inverse transform
         }
-        Fft3<G, 1>::run(v, v, u, 0, lds, p.tw);
+        Fft3<G, 1, WV>::run(v, v, u, 0, lds, p.tw);
         if (live) {
 #pragma unroll
             for (int j = 0; j < E; ++j) p.g_out[it * NY + u + T * j] = v[j].y;
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__((NY / E16) * SEQ) k_nyq(NyqArgs p) {
         const int ky = u + T * j;
         v[j] = make_float2((ky >= ry0 && ky < ry1) ? p.rows[it * NY + ky] : 0.f, 0.f);
     }
-    Fft3<G, 1>::run(v, v, u, 0, lds, p.tw);
+    Fft3<G, 1, WV>::run(v, v, u, 0, lds, p.tw);
     if (MODE == NYQ_FORWARD) {
         if (live) {
 #pragma unroll
@@ -560,8 +562,8 @@ __global__ void __launch_bounds__((NY / E16) * SEQ) k_nyq(NyqArgs p) {
         if (live && p.psd) p.psd[(it * NY + ((u + T * j + NY / 2) & (NY - 1))) * (size_t)p.nx] = pw * p.psd_scale;
         v[j] = make_float2(0.f, pw);
     }
-    __syncthreads();
-    Fft3<G, 1>::run(v, v, u, 0, lds, p.tw);
+    fft_sync<WV>();
+    Fft3<G, 1, WV>::run(v, v, u, 0, lds, p.tw);
     if (live) {
 #pragma unroll
         for (int j = 0; j < E; ++j) p.g_out[it * NY + u + T * j] = v[j].y;
@@ -616,6 +618,7 @@ template <int NX, int SEQ, int MODE, int UNIT = 0>
 __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
     using G = RowGeom<NX>;
     constexpr int T = G::T, E = E16;
+    constexpr bool WV = T <= 64;   // the transform's own exchanges are wave-local; the reductions ACROSS transforms below keep s_barrier
     __shared__ float2 lds_all[SEQ * G::LDS_ELEMS];
     const int seq = threadIdx.x / T, u = threadIdx.x % T;
     const size_t frame = blockIdx.y;
@@ -671,11 +674,11 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
             lds[NX - k] = make_float2(b.x - a.y, a.x + b.y);  // swap(conj A + i conj B)
         }
     }
-    __syncthreads();
+    fft_sync<WV>();
 #pragma unroll
     for (int j = E / 2; j < E; ++j) v[j] = lds[u + T * j];
-    __syncthreads();
-    Fft3<G, 1>::run(v, v, u, 0, lds, p.tw);
+    fft_sync<WV>();
+    Fft3<G, 1, WV>::run(v, v, u, 0, lds, p.tw);
     // v[j] = swap(z[x]), x = u + T j: row 2*pair = Re z = v.y, row 2*pair+1 = Im z = v.x
     if (MODE == C2R_PEAK) {
         if (threadIdx.x == 0) p.peak[frame] = v[0].y;
@@ -847,6 +850,9 @@ struct b4d_plan {
     float2* gbuf3 = nullptr;
     // general lengths beyond the DFT-matrix range: both axes through the fused P * A * B row transform (b4d_wiener.hip)
     bool large = false;
+    // both sides have in-register three-radix kernels (b4d_wiener_mr.hip): the transform-based entry points take those passes,
+    // whatever the size class (228-px aggregator tiles as well as 2560 x 2160 frames); tw_x / tw_y are built for it
+    bool wmr = false;
 };
 
 // b4d_general.hip

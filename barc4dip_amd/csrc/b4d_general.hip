@@ -323,7 +323,7 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
                          unsigned flags, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
     const dim3 eg((npix + 255) / 256, 1);
-    if (pl->large && wmr_supported(nx) && wmr_supported(ny)) {
+    if (pl->wmr) {
         // both sides have in-register three-radix kernels (b4d_wiener_mr.hip): forward row pairs -> transposed half spectra,
         // one pass over the columns (forward, |F|^2, inverse; the column stays in LDS), inverse row pairs + PSD rows:
         // 3 passes and ~32 bytes per pixel where the route below makes 7 passes
@@ -384,7 +384,7 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
 
 int general_fft2d(b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
-    if (pl->large && wmr_supported(nx) && wmr_supported(ny)) {   // mixed-radix kernels on both sides (b4d_wiener_mr.hip)
+    if (pl->wmr) {   // mixed-radix kernels on both sides (b4d_wiener_mr.hip)
         const size_t selems = wmr_spectrum_elems(ny, nx);
         for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
             const int nb = std::min(pl->chunk, batch - b0);
@@ -429,7 +429,7 @@ int general_fft2d_c2c(b4d_plan* pl, const float2* in, int batch, int inverse, fl
 
 int general_xcorr(b4d_plan* pl, const float* a, const float* b, int batch, float* corr, unsigned flags, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
-    if (pl->large && wmr_supported(nx) && wmr_supported(ny)) {
+    if (pl->wmr) {
         // mixed-radix kernels on both sides: two forward half-spectrum passes per operand, product + inverse columns, inverse
         // row pairs (b4d_wiener_mr.hip); the chunk buffers hold complex (chunk, ny, nx), twice a half spectrum
         const size_t selems = wmr_spectrum_elems(ny, nx);

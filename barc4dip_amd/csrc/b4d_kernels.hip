@@ -1,6 +1,7 @@
 // b4d_kernels.hip -- C ABI (include/b4d.h) of the FFT -> PSD -> autocorrelation hot path
 // (SURVEY.md §8 rows a1-a5).  Kernels live in b4d_fft2d.hpp / b4d_fft.hpp.
 #include "b4d_passes.hpp"
+#include "b4d_wiener_mr.hpp"
 
 #include <cstring>
 
@@ -69,7 +70,16 @@ static int plan_create_impl(int ny, int nx, int chunk, bool force_general, b4d_p
     if (force_general || !(pow2_ok(ny) && pow2_ok(nx))) {  // general-length plan
         p->general = true;
         p->large = !(general_ok(ny) && general_ok(nx));
+        p->wmr = wmr_supported(ny) && wmr_supported(nx);
         int rc = B4D_OK;
+        if (p->wmr && !p->large) {   // small frames on the mixed-radix passes keep their DFT matrices for the complex entry points
+            rc = make_twiddles(nx, &p->tw_x);
+            if (rc == B4D_OK) rc = make_twiddles(ny, &p->tw_y);
+        }
+        if (rc != B4D_OK) {
+            b4d_plan_destroy(p);
+            return rc;
+        }
         if (p->large) {
             rc = make_twiddles(nx, &p->tw_x);
             if (rc == B4D_OK) rc = make_twiddles(ny, &p->tw_y);

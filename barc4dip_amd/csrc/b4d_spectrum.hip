@@ -108,6 +108,7 @@ __global__ void __launch_bounds__((NX / E16) * SEQ)
 k_row_full(const float2* __restrict__ half, float2* __restrict__ out, const float2* __restrict__ tw, int ny) {
     using G = RowGeom<NX>;
     constexpr int T = G::T, E = E16;
+    constexpr bool WV = T <= 64;   // one transform per wavefront (or two): no workgroup barriers
     __shared__ float2 lds_all[SEQ * G::LDS_ELEMS];
     const int seq = threadIdx.x / T, u = threadIdx.x % T;
     const size_t frame = blockIdx.y;
@@ -120,12 +121,12 @@ k_row_full(const float2* __restrict__ half, float2* __restrict__ out, const floa
         const f32x2 q = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(src + half_pos<BLK>(u + T * j)));
         v[j] = make_float2(q.x, q.y);
     }
-    Fft3<G, 1>::run(v, v, u, 0, lds, tw);
+    Fft3<G, 1, WV>::run(v, v, u, 0, lds, tw);
     // v[j] = Z[kx = u + T j].  The second output row needs Z[-kx]: reversed through the exchange buffer.
-    __syncthreads();
+    fft_sync<WV>();
 #pragma unroll
     for (int j = 0; j < E; ++j) lds[u + T * j] = v[j];
-    __syncthreads();
+    fft_sync<WV>();
     // general row r = ky: out[ky + ny/2][c] = Z[kx], out[ny/2 - ky][c] = conj Z[-kx] at c = (kx + nx/2) % nx
     // row 0 (packed real rows ky = 0 and ny/2): out[ny/2][c] = (Z[kx] + conj Z[-kx]) / 2, out[0][c] = (Z[kx] - conj Z[-kx]) / 2i
     float2* oa = out + (frame * ny + (r == 0 ? hy : r + hy)) * (size_t)NX;

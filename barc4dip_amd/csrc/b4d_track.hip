@@ -898,7 +898,7 @@ static int wmr_phase_correlation(b4d_plan* pl, const float* images, int nimg, co
 static int general_phase_correlation(b4d_plan* pl, const float* images, int nimg, const float* tpl_src, const int32_t* tpl_frame,
                                      const int32_t* tpl_roi, int ntpl, const int32_t* pair_img, const int32_t* pair_tpl, int npairs,
                                      int subpixel, double eps, double* out, int32_t* peak_ij, hipStream_t st) {
-    if (pl->large && wmr_supported(pl->ny) && wmr_supported(pl->nx))
+    if (pl->wmr)
         return wmr_phase_correlation(pl, images, nimg, tpl_src, tpl_frame, tpl_roi, ntpl, pair_img, pair_tpl, npairs, subpixel, eps, out,
                                      peak_ij, st);
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx, nsrc = nimg + ntpl, nblk = 256;

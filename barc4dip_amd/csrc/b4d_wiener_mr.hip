@@ -32,6 +32,9 @@
 namespace b4d {
 
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+// v mod n for 0 <= v < 2 n: the fftshift / mirror columns of the store loops (a `%` by a run-time length is an integer-division
+// sequence of ~20 vector instructions PER ELEMENT)
+__device__ __forceinline__ int wrap_idx(int v, int n) { return v >= n ? v - n : v; }
 
 constexpr int WMR_Q = 4;   // row pairs per workgroup of the row kernels: 4 x 16-byte pieces = one 64-byte sector
 
@@ -498,7 +501,7 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_mag(const float2*
             const float2 z = bufq[pk_it.pos()];
             pk_it.up();
             const float ma = fabsf(z.x * g.inv), mb = fabsf(z.y * g.inv);   // conj(buf): real part row a, -imaginary part row b
-            const int c = (x + g.W / 2) % g.W;
+            const int c = wrap_idx(x + g.W / 2, g.W);
             if (act) {
                 mf[(size_t)ra * g.W + c] = ma;
                 argmax_merge(bv, bi, ma, ra * g.W + c);
@@ -614,8 +617,8 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_spec(const float2
             const float2* prow = mine + e * g.Wh;
             for (int kx = lt; kx < g.Wh; kx += L) {
                 const float2 v = prow[kx];
-                drow[(kx + g.W / 2) % g.W] = v;
-                if (kx > 0 && 2 * kx != g.W) mrow[(g.W - kx + g.W / 2) % g.W] = make_float2(v.x, -v.y);
+                drow[wrap_idx(kx + g.W / 2, g.W)] = v;
+                if (kx > 0 && 2 * kx != g.W) mrow[wrap_idx(g.W - kx + g.W / 2, g.W)] = make_float2(v.x, -v.y);
             }
         }
         __syncthreads();
@@ -695,8 +698,8 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_out(const float2*
                 const float* prow = mine + e * g.Wh;
                 for (int kx = ltq; kx < g.Wh; kx += L) {
                     const float v = prow[kx] * psd_scale;
-                    __builtin_nontemporal_store(v, drow + (kx + g.W / 2) % g.W);   // outputs are written once: streaming stores
-                    if (kx > 0 && 2 * kx != g.W) __builtin_nontemporal_store(v, mrow + (g.W - kx + g.W / 2) % g.W);
+                    __builtin_nontemporal_store(v, drow + wrap_idx(kx + g.W / 2, g.W));   // outputs are written once: streaming stores
+                    if (kx > 0 && 2 * kx != g.W) __builtin_nontemporal_store(v, mrow + wrap_idx(g.W - kx + g.W / 2, g.W));
                 }
             }
             __syncthreads();
@@ -746,7 +749,7 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_out(const float2*
             float va = z.x * se;
             const float vb = -z.y * se;   // conj(buf): real part row a, imaginary part row b
             if (unit && r0 == 0 && x == 0) va = 1.0f;
-            const int c = (x + g.W / 2) % g.W;
+            const int c = wrap_idx(x + g.W / 2, g.W);
             if (act) __builtin_nontemporal_store(va, rowa + c);
             if (has_b) __builtin_nontemporal_store(vb, rowb + c);
         }
@@ -757,6 +760,8 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_out(const float2*
 // ---- instantiated lengths -----------------------------------------------------------------------------------------
 //   4104 = 4096 + 8 (sigma 1.5 on 4k frames), 520 = 512 + 8, 264 = 256 + 8: Wiener padded sizes;
 //   2560 x 2160 (sCMOS), 1280 x 720, 600: general-size fft -> psd -> autocorr (b4d_general.hip)
+//   228, 171, 170: the tiles / sub-tiles speckle_stats and sharpness_stats cut 2048- and 512-px frames into (metrics/common.py:
+//   75-106: round(linspace) edges; 227, the other sub-tile width, is prime and stays on the DFT-matrix products)
 //   the other entries: sides of common area detectors / cameras and the powers of two that occur beside them in non-square
 //   formats (1024 x 768, 2448 x 2048, 4096 x 3000 ...); radices are picked for one round of every stage where the lanes allow
 #define B4D_WMR_LENGTHS(X)       \
@@ -797,7 +802,10 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_out(const float2*
     X(520, 8, 5, 13, 128)        \
     X(512, 8, 8, 8, 64)          \
     X(480, 8, 6, 10, 64)         \
-    X(264, 8, 3, 11, 64)
+    X(264, 8, 3, 11, 64)         \
+    X(228, 4, 3, 19, 64)         \
+    X(171, 3, 3, 19, 64)         \
+    X(170, 5, 2, 17, 64)
 
 bool wmr_supported(int n) {
 #define X(N_, A_, B_, C_, L_) \

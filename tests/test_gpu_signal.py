@@ -246,9 +246,11 @@ def test_golden_reference_vectors_64(gs, golden):
     assert nerr(gs.xcorr2d(a, b, standardize=True, normalize="none")[0], np.real(g["f32_64/xcorr2d_rm1_st1_none"])) < TOL
 
 
-@pytest.mark.parametrize("shape", [(171, 170), (228, 227), (100, 100), (33, 45), (32, 512), (2, 3)])
+@pytest.mark.parametrize("shape", [(171, 170), (228, 227), (100, 100), (33, 45), (32, 512), (2, 3), (228, 228), (170, 171),
+                                   (171, 171), (228, 170)])
 def test_general_lengths_vs_oracle(gs, shape):
-    """Any ny, nx <= 512: DFT-matrix plans (the aggregators' 170/171- and 227/228-pixel tiles)."""
+    """Any ny, nx <= 512 (the aggregators' 170/171- and 227/228-pixel tiles): DFT-matrix plans, or -- when both sides are compiled
+    mixed-radix lengths (228 = 4*3*19, 171 = 3*3*19 (odd), 170 = 5*2*17) -- the three-pass mixed-radix route."""
     from oracle import signal_np as S
 
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])

@@ -136,6 +136,9 @@ int main() {
     worst = std::max(worst, check_mix<Mix3<12, 9, 5, 64>>());
     worst = std::max(worst, check_mix<Mix3<8, 8, 8, 64>>());
     worst = std::max(worst, check_mix<Mix3<8, 6, 10, 64>>());
+    worst = std::max(worst, check_mix<Mix3<4, 3, 19, 64>>());    // 228: aggregator sub-tiles of 2048-px frames
+    worst = std::max(worst, check_mix<Mix3<3, 3, 19, 64>>());    // 171 (odd): aggregator tiles of 512-px frames
+    worst = std::max(worst, check_mix<Mix3<5, 2, 17, 64>>());    // 170
     printf(worst < 2e-6 ? "OK\n" : "FAIL\n");
     return worst < 2e-6 ? 0 : 1;
 }

@@ -13,3 +13,5 @@ static inline void __syncthreads() {}
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int min(int a, int b) { return a < b ? a : b; }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)0)
