@@ -28,6 +28,11 @@ std::recursive_mutex& scratch_mutex();
 extern std::atomic<int> g_opt_track_predict;   // "track_predict_bin" 0 / 1 / 2
 extern std::atomic<int> g_opt_exp;             // "exp": development A/B switch (kernel variants under test; 0 = shipped)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for `kernel` on the CURRENT device, set once per (kernel address, device):
+// a flag per launcher template would be per process (a second GPU of the process never gets the attribute), one per
+// function-pointer type would be shared by kernels of one signature.  Defined in b4d_kernels.hip.
+int ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 #define B4D_HIP(call)                                                                      \
     do {                                                                                   \
         hipError_t e__ = (call);                                                           \

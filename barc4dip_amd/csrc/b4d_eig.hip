@@ -545,13 +545,8 @@ extern "C" int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int 
         GramArgs g{J, G, m, ny <= nx ? nx : ny, ny <= nx ? (long long)nx : 1LL, ny <= nx ? 1LL : (long long)nx, (long long)npix, (long long)m * m};
         hipLaunchKernelGGL(k_gram_mfma, dim3(1, 1, batch), dim3(256), 0, st, g);
         B4D_HIP(hipMemsetAsync(evd, 0, sizeof(double) * 8 * batch, st));
-        static std::once_flag once;
-        static hipError_t attr_err = hipSuccess;
         const size_t lds = sizeof(double) * 2 * JS * (JS + 1);
-        std::call_once(once, [&] {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        });
-        B4D_HIP(attr_err);
+        if (int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_jacobi_small), lds)) return rc_lds;
         hipLaunchKernelGGL(k_jacobi_small, dim3(batch), dim3(1024), lds, st, G, m, evd);
         B4D_HIP(hipGetLastError());
         std::vector<double> cur((size_t)batch * 8), hstat((size_t)3 * batch);

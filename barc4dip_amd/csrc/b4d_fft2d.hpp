@@ -924,13 +924,10 @@ template <int NY, int MODE>
 static int launch_col(const ColArgs& a, int ntiles, int batch, hipStream_t st) {
     constexpr int SPLIT = (NY == 2048 && MODE == COL_PSD_AC) ? B4D_COL_SPLIT : 1;
     using Cfg = ColCfg<NY, SPLIT>;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col<NY, MODE, SPLIT, B4D_UNIT_TAG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-    });
-    B4D_HIP(attr_err);
+    {
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_col<NY, MODE, SPLIT, B4D_UNIT_TAG>), Cfg::LDS_BYTES);
+        if (rc_lds) return rc_lds;
+    }
     hipLaunchKernelGGL((k_col<NY, MODE, SPLIT, B4D_UNIT_TAG>), dim3(ntiles * SPLIT, batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     B4D_HIP(hipGetLastError());
     return B4D_OK;

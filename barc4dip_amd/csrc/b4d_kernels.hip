@@ -10,6 +10,28 @@ std::string& last_error() {
     static thread_local std::string err;
     return err;
 }
+int ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    struct Done {
+        const void* kernel;
+        int dev;
+        size_t bytes;
+    };
+    static std::mutex mu;
+    static std::vector<Done> done;
+    int dev = 0;
+    B4D_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    for (Done& d : done)
+        if (d.kernel == kernel && d.dev == dev) {
+            if (d.bytes >= bytes) return B4D_OK;
+            B4D_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            d.bytes = bytes;
+            return B4D_OK;
+        }
+    B4D_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.push_back(Done{kernel, dev, bytes});
+    return B4D_OK;
+}
 std::atomic<int> g_opt_track_predict{1};
 std::atomic<int> g_opt_exp{0};
 // b4d_spectrum.hip

@@ -149,13 +149,10 @@ template <int NY>
 static int launch_col_r2c(const float* frames, float2* half, const float2* tw, int nx, int batch, hipStream_t st) {
     using Cfg = ColR2cCfg<NY>;
     static_assert(Cfg::BLK == col_r2c_blk(NY), "the row pass reads the column order this pass writes");
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col_r2c<NY>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)Cfg::LDS_BYTES);
-    });
-    B4D_HIP(attr_err);
+    {
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_col_r2c<NY>), Cfg::LDS_BYTES);
+        if (rc_lds) return rc_lds;
+    }
     hipLaunchKernelGGL((k_col_r2c<NY>), dim3(nx / Cfg::BLK, batch), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, frames, half, tw, nx);
     B4D_HIP(hipGetLastError());
     return B4D_OK;

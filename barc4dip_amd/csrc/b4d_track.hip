@@ -275,12 +275,10 @@ __global__ void __launch_bounds__(1024) k_track_fin(FinArgs p) {
 }
 
 static int launch_track_fin(const FinArgs& fa, int pairs, hipStream_t st) {
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_fin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIN_LDS);
-    });
-    B4D_HIP(attr_err);
+    {
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_track_fin), FIN_LDS);
+        if (rc_lds) return rc_lds;
+    }
     hipLaunchKernelGGL(k_track_fin, dim3(pairs), dim3(1024), FIN_LDS, st, fa);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
@@ -383,12 +381,10 @@ __global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, SelState* __rest
 }
 
 static int launch_track_fin2(const FinArgs& fa, SelState* sel, unsigned pred, int pairs, hipStream_t st) {
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_fin2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIN_LDS);
-    });
-    B4D_HIP(attr_err);
+    {
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_track_fin2), FIN_LDS);
+        if (rc_lds) return rc_lds;
+    }
     const size_t n = (size_t)fa.ny * fa.nx;
     hipLaunchKernelGGL(k_track_select, dim3((pairs + 63) / 64), dim3(64), 0, st, n, sel, pred, pairs);
     hipLaunchKernelGGL(k_track_fin2, dim3(pairs), dim3(1024), FIN_LDS, st, fa, sel);
@@ -699,13 +695,10 @@ using namespace b4d;
 template <int NY, bool WHITEN>
 static int launch_prod(const ProdArgs& a, int nt, int pairs, hipStream_t st) {
     using Cfg = ColCfg<NY>;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_col_prod<NY, WHITEN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-    });
-    B4D_HIP(attr_err);
+    {
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_col_prod<NY, WHITEN>), Cfg::LDS_BYTES);
+        if (rc_lds) return rc_lds;
+    }
     hipLaunchKernelGGL((k_col_prod<NY, WHITEN>), dim3(nt, pairs), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     B4D_HIP(hipGetLastError());
     return B4D_OK;

@@ -838,16 +838,9 @@ static int pm_fused_launch2(const void* x, float2* out, const float2* tw, int A,
                             const FusedIO& io, hipStream_t st) {
     const bool onebuf = pm_onebuf(P, A, B);
     const size_t lds = sizeof(float2) * pm_lds_elems(P, A, B, onebuf);
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_fused<P, IN, OUT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       150 * 1024);
-        if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_fused<P, IN, OUT, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    });
-    B4D_HIP(attr_err);
+    if (int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(onebuf ? &k_pm_fused<P, IN, OUT, true> : &k_pm_fused<P, IN, OUT, false>),
+                                        150 * 1024))
+        return rc_lds;
     if (onebuf)
         hipLaunchKernelGGL((k_pm_fused<P, IN, OUT, true>), dim3(S), dim3(FT_ONEBUF), lds, st, x, out, tw, A, B, filt, conj_io, scale, io);
     else

@@ -825,14 +825,13 @@ static int wmr_cus() {
     return n;
 }
 
-// persistent row kernels: one workgroup per CU when a workgroup needs most of the LDS, as many as fit otherwise
+// persistent row kernels: one workgroup per CU when a workgroup needs most of the LDS, as many as fit otherwise.  The dynamic-LDS
+// attribute is set once per (kernel address, device): ensure_dynamic_lds (b4d_common.hpp).
 template <class MX, class K>
 static int wmr_rows_launch(K kernel, int nquads, hipStream_t st, size_t* lds_out, int* grid_out) {
     const size_t lds = wmr_rows_lds<MX>();
-    static std::once_flag once;
-    static hipError_t attr = hipSuccess;
-    std::call_once(once, [&] { attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    B4D_HIP(attr);
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
+    if (rc) return rc;
     const int per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / lds), 2048 / (WMR_Q * MX::LANES)));
     *lds_out = lds;
     *grid_out = std::min(nquads, wmr_cus() * per_cu);

@@ -367,6 +367,31 @@ def test_xcorr2d_return_type_follows_the_reference(gs, golden, name):
     assert checked > 0 or name == "f32_64"
 
 
+def test_xcorr2d_return_type_band_is_pinned_by_reference_data(gs, golden):
+    """tests/golden/xcorr_dtype.npz: the real reference on 19 shapes x 48 amplitudes returned complex128 from max|corr| = 1615 on
+    (smallest) and float64 up to 10393 (largest); outside that band its dtype depends on neither shape nor data, and there the
+    device path must return the same type (its rule: complex128 beyond 4000, inside the band).  np.argmax agrees everywhere."""
+    from oracle import signal_np as S
+
+    g = golden("xcorr_dtype.npz")
+    lo, hi = (float(v) for v in g["band"])
+    checked = 0
+    for k, (shape, seed) in enumerate(zip(g["shapes"], g["seeds"])):
+        rng = np.random.default_rng(int(seed))
+        a = rng.poisson(50.0, size=tuple(int(v) for v in shape)).astype(np.float64)
+        b = np.roll(a, (2, -3), axis=(0, 1)) + rng.normal(size=a.shape)
+        m = g["maxabs"][k]
+        below, above = np.nonzero(m < lo)[0], np.nonzero(m > hi)[0]
+        for j in (below[-1], below[len(below) // 2], above[0], above[-1]):      # next to the band on either side, and far from it
+            s_ = float(g["scales"][j])
+            got = gs.xcorr2d(a * s_, b * s_, normalize="none")[0]
+            assert np.iscomplexobj(got) == bool(g["is_complex"][k, j]), (tuple(shape), float(m[j]))
+            want = S.xcorr2d(a * s_, b * s_, normalize="none")[0]
+            assert int(np.argmax(got)) == int(np.argmax(want))
+            checked += 1
+    assert checked == 4 * len(g["shapes"])
+
+
 def test_xcorr2d_detector_counts_are_complex128(gs):
     """The normal case: un-standardised detector data -> complex128, like the reference (oracle)."""
     from oracle import signal_np as S

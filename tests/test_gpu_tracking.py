@@ -5,8 +5,9 @@ Bar: integer translation (arg-max) bit-exact.  Peak, SNR and the sub-pixel part 
 WHITENED spectrum (every bin scaled to unit modulus, so bins whose cross-power is rounding noise
 carry random phases): the reference's own float32 and float64 paths differ by ~2e-4 relative in
 the peak and ~3e-4 in SNR on these inputs (see the golden rows).  We therefore compare with the
-reference's FLOAT64 rows at rel 1e-3 (peak), 2e-3 (SNR) and abs 5e-3 px (sub-pixel part), and
-check that we are no further from float64 than 4x the reference's own float32 path."""
+reference's FLOAT64 rows with bars held at 2 x the deviation observed on MI355X (BARS below: e.g. 256^2 golden rows 9e-4
+peak, 2.2e-3 SNR, 6e-5 px sub-pixel part), and check that we are no further from float64 than 4x the reference's own
+float32 path."""
 import numpy as np
 import pytest
 
@@ -25,13 +26,39 @@ def gs():
     return signal
 
 
+# Tolerance bars of the tests below = 2 x the largest deviation observed on MI355X (round 3, tests/conftest.py::observe writes the
+# maxima of every run to gpurun_out/observed_tolerances.json; DESIGN.md section 5 holds the table).  Keys: <test>/<quantity>.
+BARS = {   # observed maximum in the comment
+    "golden_rows_256/sub_px": 6e-5,    # 2.7e-5 px   (256^2, 36 golden rows of the reference, float64 protocol)
+    "golden_rows_256/peak_rel": 9e-4,  # 4.4e-4
+    "golden_rows_256/snr_rel": 2.2e-3,  # 1.07e-3    (61-px templates: the whitened spectrum leaves rounding noise undamped)
+    "batch_512/sub_px": 1.4e-4,        # 6.6e-5 px   (512^2, 90 pairs)
+    "batch_512/peak_rel": 5.5e-4,      # 2.6e-4
+    "batch_512/snr_rel": 1.5e-3,       # 7.2e-4
+    "general_sizes/sub_px": 1.4e-4,    # 6.7e-5 px   (200x300 ... 1080x1920: DFT-matrix and mixed-radix routes)
+    "general_sizes/peak_rel": 6.5e-4,  # 3.0e-4
+    "general_sizes/snr_rel": 1.3e-3,   # 6.2e-4
+    "all_routes/sub_px": 3e-5,         # 1.5e-5 px   (64^2 ... 4096x1024, three median routes)
+    "all_routes/peak_rel": 1.2e-3,     # 5.6e-4
+    "all_routes/snr_rel": 1.3e-3,      # 6.1e-4
+    # NCC template matching: float32 rounding level (observed 1.2e-7 ... 4.8e-7); the floor is held at 2e-6 rather than 2 x that
+    "ncc_256/peak_abs": 2e-6, "ncc_256/sub_px": 2e-6, "ncc_256/snr_rel": 2e-6,
+    "ncc_batch/peak_abs": 2e-6,
+    "ncc_mixed/sub_px": 2e-6, "ncc_mixed/peak_abs": 2e-6, "ncc_mixed/snr_rel": 2e-6,
+}
+
+
+def _rel(got, want):
+    return abs(got - want) / abs(want)
+
+
 def _inputs():
     i0 = synth.speckle_intensity(256, 1234)
     f0 = np.random.default_rng(1).poisson(i0).astype(np.float32)
     return i0, f0
 
 
-def test_golden_rows_256(gs, golden):
+def test_golden_rows_256(gs, golden, observe):
     from barc4dip_amd.geometry import roi_slices
 
     g = golden("tracking.npz")
@@ -53,9 +80,9 @@ def test_golden_rows_256(gs, golden):
         if not sub:
             assert dy == rdy and dx == rdx                      # integer outputs: bit exact
         else:
-            assert abs(dy - rdy) < 5e-3 and abs(dx - rdx) < 5e-3
-        assert peak == pytest.approx(rpeak, rel=1e-3)
-        assert snr == pytest.approx(rsnr, rel=2e-3)
+            observe("golden_rows_256/sub_px", max(abs(dy - rdy), abs(dx - rdx)), BARS["golden_rows_256/sub_px"])
+        observe("golden_rows_256/peak_rel", _rel(peak, rpeak), BARS["golden_rows_256/peak_rel"])
+        observe("golden_rows_256/snr_rel", _rel(snr, rsnr), BARS["golden_rows_256/snr_rel"])
         own = ref32[(k, sy, sx, side, cy, cx, sub)]            # the reference's float32 path on the same input
         assert abs(peak - rpeak) <= 4 * abs(own[2] - rpeak) + 1e-6 * rpeak
         checked += 1
@@ -91,7 +118,7 @@ def test_dispatcher_errors_and_defaults(gs, golden):
     assert round(r[0]) == round(ref[0]) == 2 and round(r[1]) == round(ref[1]) == -3
 
 
-def test_batch_matches_oracle_and_truth(gs):
+def test_batch_matches_oracle_and_truth(gs, observe):
     """cfg3 protocol at reduced T: 3x3 ROI grid, abs + inc templates, all shifts recovered integer-exact."""
     from barc4dip_amd.geometry import roi_grid_3x3
     from oracle import signal_np as S
@@ -124,9 +151,9 @@ def test_batch_matches_oracle_and_truth(gs):
         mag = S.phase_correlation_map(stack[tpl_frame[pair_tpl[i]]][sl], stack[pair_img[i]], slices_yx=sl)
         mi, mj = np.unravel_index(np.argmax(mag), mag.shape)
         assert (pij[i, 0], pij[i, 1]) == (mi, mj)                      # index output: bit exact
-        assert abs(res[i, 0] - ref[0]) < 5e-3 and abs(res[i, 1] - ref[1]) < 5e-3
-        assert res[i, 2] == pytest.approx(ref[2], rel=1e-3)
-        assert res[i, 3] == pytest.approx(ref[3], rel=2e-3)
+        observe("batch_512/sub_px", max(abs(res[i, 0] - ref[0]), abs(res[i, 1] - ref[1])), BARS["batch_512/sub_px"])
+        observe("batch_512/peak_rel", _rel(res[i, 2], ref[2]), BARS["batch_512/peak_rel"])
+        observe("batch_512/snr_rel", _rel(res[i, 3], ref[3]), BARS["batch_512/snr_rel"])
     # ground truth: abs shifts equal the imposed spiral, inc shifts its differences
     abs_dy = res[:T * 9, 0].reshape(T, 9)
     abs_dx = res[:T * 9, 1].reshape(T, 9)
@@ -161,10 +188,9 @@ def test_xcorr2d(gs, rm, nm):
 
 
 @pytest.mark.parametrize("backend", ["opencv", "skimage"])
-def test_template_matching_vs_oracle(gs, backend):
+def test_template_matching_vs_oracle(gs, backend, observe):
     """NCC template matching (signal/tracking.py:81-188) against the float64 oracle (parity with cv2 / scikit-image is
-    unpinned).  Integer arg-max exact; peak within 2e-4 (float32 FFT correlation of ~1e3-count data), sub-pixel
-    shift within 2e-3 px (the Taylor step divides differences of nearly equal float32 map values), snr within 1e-3."""
+    unpinned).  Integer arg-max exact; peak, sub-pixel shift and snr at float32 rounding level (observed <= 5e-7, bars 2e-6)."""
     from barc4dip_amd import synth
     from oracle import ncc_np as N
 
@@ -178,21 +204,21 @@ def test_template_matching_vs_oracle(gs, backend):
         wi = N.template_matching(f0[sl], fr, slices_yx=sl, backend=backend, subpixel=False)
         gi = gs.template_matching(f0[sl], fr, slices_yx=sl, backend=backend, subpixel=False)
         assert (gi[0], gi[1]) == (wi[0], wi[1])                       # integer part: bit-exact
-        assert got[2] == pytest.approx(want[2], abs=2e-4)
-        assert got[0] == pytest.approx(want[0], abs=2e-3) and got[1] == pytest.approx(want[1], abs=2e-3)
-        assert got[3] == pytest.approx(want[3], rel=1e-3)
+        observe("ncc_256/peak_abs", abs(got[2] - want[2]), BARS["ncc_256/peak_abs"])
+        observe("ncc_256/sub_px", max(abs(got[0] - want[0]), abs(got[1] - want[1])), BARS["ncc_256/sub_px"])
+        observe("ncc_256/snr_rel", _rel(got[3], want[3]), BARS["ncc_256/snr_rel"])
     # template referenced to a position it was not cut from (slices None -> centred reference), odd size
     tpl = f0[30:71, 50:91]
     want = N.template_matching(tpl, f0, backend=backend)
     got = gs.template_matching(tpl, f0, backend=backend)
-    assert got[0] == pytest.approx(want[0], abs=2e-3) and got[1] == pytest.approx(want[1], abs=2e-3)
+    observe("ncc_256/sub_px", max(abs(got[0] - want[0]), abs(got[1] - want[1])), BARS["ncc_256/sub_px"])
     with pytest.raises(ValueError):
         gs.template_matching(np.zeros((300, 10), np.float32), f0)
     with pytest.raises(ValueError):
         gs.template_matching(tpl, f0, backend="internal")
 
 
-def test_template_matching_batch_map_and_truth(gs):
+def test_template_matching_batch_map_and_truth(gs, observe):
     """Batched call: every (frame, ROI) pair recovers its integer shift; arg-max indices equal the oracle's."""
     from barc4dip_amd import synth
     from oracle import ncc_np as N
@@ -208,11 +234,11 @@ def test_template_matching_batch_map_and_truth(gs):
         assert (res[i, 0], res[i, 1]) == (sh[t][0], sh[t][1])
         corr = N.match_template_ncc(stack[t], N.S.zscore2d(stack[0][y0:y1, x0:x1], 1e-9).astype(np.float32))
         assert tuple(pij[i]) == np.unravel_index(int(np.argmax(corr)), corr.shape)
-        assert res[i, 2] == pytest.approx(float(corr.max()), abs=2e-4)
+        observe("ncc_batch/peak_abs", abs(res[i, 2] - float(corr.max())), BARS["ncc_batch/peak_abs"])
 
 
 @pytest.mark.parametrize("shape", [(200, 300), (171, 170), (600, 720), (720, 600), (720, 1280), (1080, 1920)])   # the last four: mixed-radix kernels
-def test_phase_correlation_general_sizes(gs, shape):
+def test_phase_correlation_general_sizes(gs, shape, observe):
     """Phase correlation on frames that are not a power of two (DFT-matrix / fused mixed-radix plans) against the
     oracle: integer arg-max exact, sub-pixel shift / peak within the float32 bar of the power-of-two path."""
     from oracle import signal_np as S
@@ -231,13 +257,14 @@ def test_phase_correlation_general_sizes(gs, shape):
         assert (gi[0], gi[1]) == (wi[0], wi[1])            # integer output: equal to the reference's, whatever it finds
         if shape[0] <= 600:                                # (on the 720-row crops the reference itself loses some of these
             assert (gi[0], gi[1]) == (dy, dx)              #  61 / 41-px templates to noise: only parity is asserted there)
-        assert got[0] == pytest.approx(want[0], abs=5e-3) and got[1] == pytest.approx(want[1], abs=5e-3)
-        assert got[2] == pytest.approx(want[2], rel=1e-3) and got[3] == pytest.approx(want[3], rel=2e-3)
+        observe("general_sizes/sub_px", max(abs(got[0] - want[0]), abs(got[1] - want[1])), BARS["general_sizes/sub_px"])
+        observe("general_sizes/peak_rel", _rel(got[2], want[2]), BARS["general_sizes/peak_rel"])
+        observe("general_sizes/snr_rel", _rel(got[3], want[3]), BARS["general_sizes/snr_rel"])
 
 
 @pytest.mark.parametrize("shape", [(64, 64), (128, 256), (2048, 512), (512, 2048), (2048, 2048), (4096, 1024),
                                    (600, 720), (1080, 1920), (767, 1024), (1024, 768)])   # the last four: mixed-radix kernels (767: fused route)
-def test_phase_correlation_power_of_two_sizes_all_routes(gs, shape):
+def test_phase_correlation_power_of_two_sizes_all_routes(gs, shape, observe):
     """Every row-kernel geometry of the power-of-two route (1 to 32 row pairs per workgroup, 1 to 3 workgroups for the rows
     around the peak) and the mixed-radix route (quads of row pairs, odd heights) with the median expectation on (map-free pass
     + rows around the peak), off (full map) and deliberately wrong (gated full-map pass): bit-identical rows, and parity with
@@ -266,8 +293,9 @@ def test_phase_correlation_power_of_two_sizes_all_routes(gs, shape):
     want = S.phase_correlation(base[sl], fr, slices_yx=sl)
     wi = S.phase_correlation(base[sl], fr, slices_yx=sl, subpixel=False)
     assert (got[1][1][0], got[1][1][1]) == (wi[0], wi[1]) == (dy, dx)
-    assert got[1][0][0] == pytest.approx(want[0], abs=5e-3) and got[1][0][1] == pytest.approx(want[1], abs=5e-3)
-    assert got[1][0][2] == pytest.approx(want[2], rel=1e-3) and got[1][0][3] == pytest.approx(want[3], rel=2e-3)
+    observe("all_routes/sub_px", max(abs(got[1][0][0] - want[0]), abs(got[1][0][1] - want[1])), BARS["all_routes/sub_px"])
+    observe("all_routes/peak_rel", _rel(got[1][0][2], want[2]), BARS["all_routes/peak_rel"])
+    observe("all_routes/snr_rel", _rel(got[1][0][3], want[3]), BARS["all_routes/snr_rel"])
 
 
 def synth_frame(n, seed):
@@ -306,7 +334,7 @@ def test_sharded_tracking_equals_single_rank(gs):
     assert np.array_equal(tr["dy_inc"][1:, 0], np.diff(sh[:, 0])) and np.array_equal(tr["dx_inc"][1:, 0], np.diff(sh[:, 1]))
 
 
-def test_template_matching_mixed_template_sizes(gs):
+def test_template_matching_mixed_template_sizes(gs, observe):
     """One batched call with templates of different shapes (every pair has its own match-map geometry)."""
     from barc4dip_amd import synth
     from oracle import ncc_np as N
@@ -320,8 +348,9 @@ def test_template_matching_mixed_template_sizes(gs):
     for i, (t, k) in enumerate(zip(pair_img, pair_tpl)):
         y0, y1, x0, x1 = rois[k]
         want = N.template_matching(stack[0][y0:y1, x0:x1], stack[t], slices_yx=(slice(y0, y1), slice(x0, x1)), backend="opencv")
-        assert res[i, 0] == pytest.approx(want[0], abs=3e-3) and res[i, 1] == pytest.approx(want[1], abs=3e-3), (t, k)
-        assert res[i, 2] == pytest.approx(want[2], abs=2e-4) and res[i, 3] == pytest.approx(want[3], rel=1e-3)
+        observe("ncc_mixed/sub_px", max(abs(res[i, 0] - want[0]), abs(res[i, 1] - want[1])), BARS["ncc_mixed/sub_px"])
+        observe("ncc_mixed/peak_abs", abs(res[i, 2] - want[2]), BARS["ncc_mixed/peak_abs"])
+        observe("ncc_mixed/snr_rel", _rel(res[i, 3], want[3]), BARS["ncc_mixed/snr_rel"])
         assert (round(res[i, 0]), round(res[i, 1])) == (sh[t][0], sh[t][1])
 
 

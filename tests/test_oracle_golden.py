@@ -51,6 +51,28 @@ def test_xcorr_autocorr_bit_exact(golden, name):
     np.testing.assert_array_equal(yl, g[f"{name}/ylag"])
 
 
+def _xcorr_dtype_inputs(shape, seed):
+    """The seeded pair of oracle/make_golden_xcorr_dtype.py."""
+    rng = np.random.default_rng(int(seed))
+    a = rng.poisson(50.0, size=tuple(int(v) for v in shape)).astype(np.float64)
+    b = np.roll(a, (2, -3), axis=(0, 1)) + rng.normal(size=a.shape)
+    return a, b
+
+
+def test_xcorr2d_return_type_sweep(golden):
+    """np.real_if_close decides xcorr2d's dtype on rounding noise (signal/corr.py:41-42, 242): the oracle performs the reference's
+    arithmetic, so it reproduces the reference's dtype at EVERY amplitude of the sweep -- inside the data-dependent band as well."""
+    g = golden("xcorr_dtype.npz")
+    lo, hi = g["band"]
+    assert 1000 < lo < 4000 < hi < 20000        # the product's rule (complex128 beyond max|corr| = 4000) sits inside the band
+    for k, (shape, seed) in enumerate(zip(g["shapes"], g["seeds"])):
+        a, b = _xcorr_dtype_inputs(shape, seed)
+        for j in range(0, len(g["scales"]), 5):
+            c = S.xcorr2d(a * g["scales"][j], b * g["scales"][j], normalize="none")[0]
+            assert np.iscomplexobj(c) == bool(g["is_complex"][k, j]), (tuple(shape), j)
+            assert float(np.max(np.abs(c))) == pytest.approx(float(g["maxabs"][k, j]), rel=1e-12)
+
+
 def test_1d_helpers(golden):
     g = golden("signal_small.npz")
     a, b = g["1d/a"], g["1d/b"]
