@@ -790,7 +790,10 @@ struct b4d_wiener {
     // mixed-radix route (b4d_wiener_mr.hip): both padded sides have a compiled three-radix kernel
     bool mr = false;
     WmrGeom geom{};
-    float2* mr_filt = nullptr;   // (Wh, Hp) transposed half filter
+    float2* mr_filt = nullptr;   // (Wh, Hp) transposed half filter (general PSF)
+    float2* mr_sepx = nullptr;   // separable, point-symmetric PSF (the Gaussian of deconvolve_psf): {hx, lx}[Wh] and {hy, ly}[H] instead,
+    float2* mr_sepy = nullptr;   // the filter is rebuilt per element in the column pass (b4d_wiener_mr.hip: WmrSep)
+    float mr_balance = 0.f;
     float2* mr_T = nullptr;      // (mr_cap, Wh, Hp) transposed half spectra of the frames of one launch
     float* mr_amax = nullptr;    // (mr_cap * (hp + 1)): max|frame| per frame, then the pair maxima
     int mr_cap = 0;
@@ -1101,7 +1104,7 @@ extern "C" {
 int b4d_wiener_destroy(b4d_wiener* p) {
     if (!p) return B4D_OK;
     for (void* q : {(void*)p->twx, (void*)p->twy, (void*)p->dmx, (void*)p->dmy, (void*)p->filt, (void*)p->a, (void*)p->b, (void*)p->c,
-                    (void*)p->padded, (void*)p->amax, (void*)p->mr_filt, (void*)p->mr_T, (void*)p->mr_amax})
+                    (void*)p->padded, (void*)p->amax, (void*)p->mr_filt, (void*)p->mr_T, (void*)p->mr_amax, (void*)p->mr_sepx, (void*)p->mr_sepy})
         if (q) (void)hipFree(q);
     for (int l = 0; l < B4D_WIENER_LANES; ++l) {
         b4d_wiener::Lane& L = p->lane[l];
@@ -1199,11 +1202,50 @@ int b4d_wiener_create(int h, int w, const float* psf_host, int ky, int kx, float
         g.hp = (p->H + 1) / 2;
         g.clip = 0;
         g.inv = 1.0f / ((float)p->H * (float)p->W);
-        e = hipMalloc((void**)&p->mr_filt, sizeof(float2) * (size_t)g.Wh * g.Hp);
-        if (e == hipSuccess) e = hipMemset(p->mr_filt, 0, sizeof(float2) * (size_t)g.Wh * g.Hp);
-        if (e == hipSuccess)
-            e = hipMemcpy2D(p->mr_filt, sizeof(float2) * g.Hp, p->filt, sizeof(float2) * p->H, sizeof(float2) * p->H, g.Wh,
-                            hipMemcpyDeviceToDevice);
+        // Separable (rank one) and point-symmetric kernel?  psf = u v^T / s with u = row sums, v = column sums, s = total; then the
+        // transfer function is the real product hx[k] hy[ky] of two cosine sums and the column pass needs no filter table at all.
+        std::vector<double> u(ky, 0.0), v(kx, 0.0);
+        double tot = 0.0, amaxk = 0.0;
+        for (int i = 0; i < ky; ++i)
+            for (int j = 0; j < kx; ++j) {
+                const double q = psf_host[i * kx + j];
+                u[i] += q;
+                v[j] += q;
+                tot += q;
+                amaxk = std::max(amaxk, std::fabs(q));
+            }
+        bool sep = tot != 0.0 && std::getenv("B4D_WIENER_TABLE") == nullptr;
+        for (int i = 0; i < ky && sep; ++i) {
+            if (std::fabs(u[i] - u[ky - 1 - i]) > 1e-7 * std::fabs(tot)) sep = false;
+            for (int j = 0; j < kx && sep; ++j)
+                if (std::fabs(psf_host[i * kx + j] * tot - u[i] * v[j]) > 2e-6 * amaxk * std::fabs(tot)) sep = false;
+        }
+        for (int j = 0; j < kx && sep; ++j)
+            if (std::fabs(v[j] - v[kx - 1 - j]) > 1e-7 * std::fabs(tot)) sep = false;
+        if (sep) {
+            std::vector<float2> sx(g.Wh), sy(p->H);
+            for (int n = 0; n < p->H; ++n) {
+                double hy = 0.0;
+                for (int i = 0; i < ky; ++i) hy += u[i] * std::cos(2.0 * M_PI * (double)n * (double)(i - ky / 2) / (double)p->H);
+                sy[n] = make_float2((float)hy, (float)(2.0 - 2.0 * std::cos(2.0 * M_PI * (double)n / (double)p->H)));
+            }
+            for (int k = 0; k < g.Wh; ++k) {
+                double hx = 0.0;
+                for (int j = 0; j < kx; ++j) hx += v[j] / tot * std::cos(2.0 * M_PI * (double)k * (double)(j - kx / 2) / (double)p->W);
+                sx[k] = make_float2((float)hx, (float)(2.0 - 2.0 * std::cos(2.0 * M_PI * (double)k / (double)p->W)));
+            }
+            e = hipMalloc((void**)&p->mr_sepx, sizeof(float2) * sx.size());
+            if (e == hipSuccess) e = hipMalloc((void**)&p->mr_sepy, sizeof(float2) * sy.size());
+            if (e == hipSuccess) e = hipMemcpy(p->mr_sepx, sx.data(), sizeof(float2) * sx.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(p->mr_sepy, sy.data(), sizeof(float2) * sy.size(), hipMemcpyHostToDevice);
+            p->mr_balance = balance;
+        } else {
+            e = hipMalloc((void**)&p->mr_filt, sizeof(float2) * (size_t)g.Wh * g.Hp);
+            if (e == hipSuccess) e = hipMemset(p->mr_filt, 0, sizeof(float2) * (size_t)g.Wh * g.Hp);
+            if (e == hipSuccess)
+                e = hipMemcpy2D(p->mr_filt, sizeof(float2) * g.Hp, p->filt, sizeof(float2) * p->H, sizeof(float2) * p->H, g.Wh,
+                                hipMemcpyDeviceToDevice);
+        }
         if (e != hipSuccess) rc = fail(B4D_ENOMEM, std::string("wiener filter (mixed-radix route): ") + hipGetErrorString(e));
         if (rc == B4D_OK) {
             for (float2** q : {&p->filt, &p->a, &p->b, &p->c}) {
@@ -1246,7 +1288,7 @@ static int wiener_mr_apply(b4d_wiener* p, const float* frames, int batch, float*
         int rc;
         float* pmax = p->mr_amax + p->mr_cap;
         if ((rc = wmr_rows_fwd(frames + b0 * fp, p->mr_T, p->twx, pmax, g, nf, st))) return rc;
-        if ((rc = wmr_cols(p->mr_T, p->mr_filt, p->twy, pmax, p->mr_amax, g, nf, st))) return rc;
+        if ((rc = wmr_cols(p->mr_T, p->mr_filt, p->twy, pmax, p->mr_amax, g, nf, st, p->mr_sepx, p->mr_sepy, p->mr_balance))) return rc;
         if ((rc = wmr_rows_inv(p->mr_T, out + b0 * fp, p->twx, p->mr_amax, g, nf, st))) return rc;
     }
     return B4D_OK;

@@ -178,11 +178,19 @@ __global__ void __launch_bounds__(WMR_Q* MX::LANES) k_wmr_rows_fwd(const float* 
 // is stored as a REAL column to Pt (same [k][ky] layout, pitch g.Hp floats) when Pt != null, and is what the inverse
 // transform runs on (skipped when `inverse` == 0: PSD only).  MODE 2: forward transform only, F written back in natural
 // order (the 2-D half spectra of images / templates for tracking and xcorr2d).
+// MODE 0 with sep.y != null: the filter of a SEPARABLE, point-symmetric PSF (the Gaussian of deconvolve_psf) is not streamed from a
+// (Wh, Hp) table but rebuilt per element from two 1-D tables -- H(k, ky) = hx[k] hy[ky] (real), Laplacian L = lx[k] + ly[ky],
+// W = H / (H^2 + balance L^2) -- 67 MB per 4k frame that never cross HBM (the tables are 49 KB and stay in L2).
+struct WmrSep {
+    const float2* x;   // (Wh): {hx[k], lx[k]}
+    const float2* y;   // (H):  {hy[ky], ly[ky]}
+    float balance;
+};
 template <class MY, int MODE>
 __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ T, const float2* __restrict__ filt,
                                                             const float2* __restrict__ twN, const float* __restrict__ pmax,
                                                             float* __restrict__ amax, WmrGeom g, float* __restrict__ Pt, unsigned flags,
-                                                            int inverse) {
+                                                            int inverse, WmrSep sep) {
     __shared__ __attribute__((aligned(16))) float2 buf[MY::BUF];
     __shared__ float2 tw2[MY::M1];
     constexpr int R1 = MY::R1, M1 = MY::M1, LANES = MY::LANES, RD = MY::ROUNDS1, N = MY::N;
@@ -190,7 +198,9 @@ __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ 
     const int col = blockIdx.x;
     const int f = col / g.Wh, k = col - f * g.Wh;
     float2* x = T + (size_t)col * g.Hp;
-    const float2* fl = MODE == 0 ? filt + (size_t)k * g.Hp : nullptr;
+    const float2* fl = MODE == 0 ? (sep.y ? sep.y : filt + (size_t)k * g.Hp) : nullptr;
+    float2 sx = make_float2(0.f, 0.f);
+    if (MODE == 0 && sep.y) sx = sep.x[k];
     MY::build_tw2(tw2, twN, tid);
     if (MODE == 0 && k == 0 && tid < 64) {   // max|frame| from the pair maxima of k_wmr_rows_fwd (fmaxf drops NaN: np.nanmax)
         float mx = 0.f;
@@ -242,8 +252,15 @@ __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ 
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
             if (MODE == 0) {
-                const float2 p = cmul(buf[pi.pos()], fv[r][n1]);
-                v[r][n1] = make_float2(p.x, -p.y);
+                if (sep.y) {   // fv = {hy, ly} of this row: W = t / (t^2 + balance s^2), t = hx hy, s = lx + ly (real)
+                    const float t = sx.x * fv[r][n1].x, sl = sx.y + fv[r][n1].y;
+                    const float wv = t / fmaf(t, t, sep.balance * sl * sl);
+                    const float2 b = buf[pi.pos()];
+                    v[r][n1] = make_float2(b.x * wv, -(b.y * wv));
+                } else {
+                    const float2 p = cmul(buf[pi.pos()], fv[r][n1]);
+                    v[r][n1] = make_float2(p.x, -p.y);
+                }
             } else {
                 const float2 f = buf[pi.pos()];
                 const int n = M1 * n1 + mc;
@@ -859,13 +876,13 @@ int wmr_rows_fwd(const float* frames, float2* T, const float2* twx, float* pmax,
 
 template <int MODE>
 static int wmr_cols_launch(float2* T, const float2* filt, const float2* twy, const float* pmax, float* amax, const WmrGeom& g,
-                           int nframes, float* Pt, unsigned flags, int inverse, hipStream_t st) {
+                           int nframes, float* Pt, unsigned flags, int inverse, hipStream_t st, WmrSep sep = WmrSep{nullptr, nullptr, 0.f}) {
     const unsigned grid = (unsigned)nframes * (unsigned)g.Wh;
     switch (g.H) {
 #define X(N_, A_, B_, C_, L_)                                                                                                            \
     case N_:                                                                                                                             \
         hipLaunchKernelGGL((k_wmr_cols<Mix3<A_, B_, C_, L_>, MODE>), dim3(grid), dim3(L_), 0, st, T, filt, twy, pmax, amax, g, Pt, flags, \
-                           inverse);                                                                                                     \
+                           inverse, sep);                                                                                                \
         break;
         B4D_WMR_LENGTHS(X)
 #undef X
@@ -876,8 +893,8 @@ static int wmr_cols_launch(float2* T, const float2* filt, const float2* twy, con
 }
 
 int wmr_cols(float2* T, const float2* filt, const float2* twy, const float* pmax, float* amax, const WmrGeom& g, int nframes,
-             hipStream_t st) {
-    return wmr_cols_launch<0>(T, filt, twy, pmax, amax, g, nframes, nullptr, 0u, 1, st);
+             hipStream_t st, const float2* sep_x, const float2* sep_y, float balance) {
+    return wmr_cols_launch<0>(T, filt, twy, pmax, amax, g, nframes, nullptr, 0u, 1, st, WmrSep{sep_x, sep_y, balance});
 }
 
 int wmr_psd_autocorr(const float* frames, int nframes, int ny, int nx, const float2* twx, const float2* twy, float2* T, float* Pt,

@@ -28,8 +28,10 @@ int wmr_psd_autocorr(const float* frames, int nframes, int ny, int nx, const flo
 int wmr_rows_fwd(const float* frames, float2* T, const float2* twx, float* pmax, const WmrGeom& g, int nframes, hipStream_t st);
 // every column of T: forward transform, times filt (Wh, Hp), inverse transform (unscaled), in place;
 // amax[f] = max|frame f| reduced from pmax
+// sep_y != null: `filt` is not read; the filter of a separable, point-symmetric PSF is rebuilt per element from sep_x (Wh) =
+// {hx[k], lx[k]} and sep_y (H) = {hy[ky], ly[ky]}: W = hx hy / ((hx hy)^2 + balance (lx + ly)^2)
 int wmr_cols(float2* T, const float2* filt, const float2* twy, const float* pmax, float* amax, const WmrGeom& g, int nframes,
-             hipStream_t st);
+             hipStream_t st, const float2* sep_x = nullptr, const float2* sep_y = nullptr, float balance = 0.f);
 // T -> out (nframes, h, w): inverse row transforms, 1/(H W), normalise by max|frame|, clip, rescale, crop
 int wmr_rows_inv(const float2* T, float* out, const float2* twx, const float* amax, const WmrGeom& g, int nframes, hipStream_t st);
 
