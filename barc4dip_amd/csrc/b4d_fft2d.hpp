@@ -614,10 +614,6 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
 //   C2R_OUT   shifted real output, scaled (flags & NORM_PEAK: by 1/peak[frame], zero lag forced to 1)
 //   C2R_PEAK  only the zero-lag value of each frame -> peak[frame]
 //   C2R_MAG   |value| * scale (signal/tracking.py:283-285) + per-workgroup arg-max partials
-#ifndef B4D_EXP_PLAIN_MAG
-#define B4D_EXP_PLAIN_MAG 0
-#endif
-constexpr bool g_exp_dev = B4D_EXP_PLAIN_MAG;
 template <int NX, int SEQ, int MODE, int UNIT = 0>
 __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
     using G = RowGeom<NX>;
@@ -667,9 +663,8 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
         const int k = u + T * j;
         const size_t o = spec_index(frame, nt, ny, ct_w, yl, k);
         // read once, written once: streaming hints on both sides of the row pass (-4 % on the cfg2 kernel)
-        const f32x2* ga = reinterpret_cast<const f32x2*>(p.g + o);
-        const f32x2 a_ = (MODE == C2R_MAG && g_exp_dev) ? ga[0] : __builtin_nontemporal_load(ga),
-                    b_ = (MODE == C2R_MAG && g_exp_dev) ? ga[ct_w] : __builtin_nontemporal_load(ga + ct_w);
+        const f32x2 a_ = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.g + o)),
+                    b_ = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.g + o + ct_w));
         const float2 a = make_float2(a_.x, a_.y), b = make_float2(b_.x, b_.y);
         if (k == 0) {  // DC and Nyquist bins of both rows are real
             v[j] = make_float2(b.x, a.x);                                                       // swap(A_dc + i B_dc)
