@@ -87,7 +87,7 @@ def fft2d_stack(stack, *, return_tensors: bool = False):
     torch = _ffi.require_gpu()
     t, _, src = _frames(stack, (3,))
     T, ny, nx = t.shape
-    pl = _ffi.get_plan(ny, nx)
+    pl = _ffi.get_plan(ny, nx, _ffi.stack_chunk(ny, nx, int(T)))
     out = torch.empty((T, ny, nx), dtype=torch.complex64, device=t.device)
     _ffi.check(_ffi.lib().b4d_fft2d(pl.handle, D.ptr(t), int(T), D.ptr(out), _ffi.stream_ptr()))
     return _finish(out, True, return_tensors, np.complex128 if src is np.float64 else np.complex64)

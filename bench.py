@@ -129,7 +129,7 @@ def secondary_fft2d(torch, stack, cpu: bool):
     4 + 4 B per pixel; rows of it -> every output row and its conjugate mirror, 4 + 8 B per pixel)."""
     from barc4dip_amd.signal.fft import fft2d_stack
 
-    T, n = min(int(stack.shape[0]), 128), int(stack.shape[-1])
+    T, n = min(int(stack.shape[0]), 256), int(stack.shape[-1])
     sub = stack[:T]
     res = {}
 
