@@ -15,6 +15,11 @@ and ``b4d_temporal_finalize_dev`` reads it from device memory, so the host never
 then its slice of ``buf`` is all-reduced on a side stream while block c + 1 is still being accumulated
 (the collective is 4-25 % of a cfg4 step at 8 GPUs) -- k collectives of 1/k of the payload each,
 the first one carrying the count.
+
+``collective="reduce_scatter"`` is SURVEY.md §8e's all-links alternative: the image rows are cut into one equal slice per rank,
+ONE reduce-scatter leaves every rank with the summed [count, sum_x, sum_xx] of ITS slice (1/N of the all-reduce's payload per
+link direction), each rank finalises its slice, and ONE all-gather of the three float32 maps (12 instead of 16 bytes per pixel)
+rebuilds them everywhere.  Same sums, same finalisation kernel: the maps are bit-identical to the all-reduce route's.
 """
 from __future__ import annotations
 
@@ -86,20 +91,92 @@ class TemporalSums:
             _ffi.stream_ptr()))
 
 
+def scatter_layout(H: int, W: int, world: int):
+    """Row slices of the reduce-scatter route: `world` equal slices of `rows` image rows (the last ones padded), each packed as
+    [count, pad, sum_x (rows W), sum_xx (rows W)] so that every rank's share of the reduce-scatter carries the frame count."""
+    rows = -(-int(H) // int(world))
+    return rows, TemporalSums.HEAD + 2 * rows * int(W)
+
+
+def _reduce_scatter(dist, out, inp, group):
+    """out = this rank's slice of sum over ranks of inp.  RCCL ("nccl") has the collective; gloo (the CPU logic tests) does not in
+    every build: there the same result comes from an all-reduce and a slice."""
+    try:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+    except (RuntimeError, NotImplementedError):
+        if dist.get_backend(group) != "gloo":
+            raise
+        dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=group)
+        r = dist.get_rank(group)
+        out.copy_(inp[r * out.numel():(r + 1) * out.numel()])
+
+
+def _temporal_stats_scatter(torch, dist, group, t, chunk, timings):
+    """The reduce-scatter + all-gather route of temporal_stats (module docstring)."""
+    T, H, W = (int(v) for v in t.shape)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rows, per = scatter_layout(H, W, world)
+    buf = torch.zeros(world * per, dtype=torch.float64, device=t.device)
+    buf.view(world, per)[:, 0] = float(T)
+    lib, st = _ffi.lib(), _ffi.stream_ptr()
+    for r in range(world):
+        r0, r1 = r * rows, min((r + 1) * rows, H)
+        if r1 <= r0:
+            continue
+        o = r * per + TemporalSums.HEAD
+        for a in range(0, T, chunk):
+            fr = t[a:a + chunk]
+            _ffi.check(lib.b4d_temporal_accumulate_range(C.c_void_p(fr.data_ptr()), int(fr.shape[0]), H * W, r0 * W, (r1 - r0) * W,
+                                                         C.c_void_p(buf[o:].data_ptr()), C.c_void_p(buf[o + rows * W:].data_ptr()), st))
+    mine = torch.empty(per, dtype=torch.float64, device=t.device)
+    ev = None
+    if timings is not None:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+    _reduce_scatter(dist, mine, buf, group)
+    if ev:
+        ev[1].record()
+    maps = torch.zeros((3, rows * W), dtype=torch.float32, device=t.device)
+    sx, sxx = mine[TemporalSums.HEAD:TemporalSums.HEAD + rows * W], mine[TemporalSums.HEAD + rows * W:]
+    _ffi.check(lib.b4d_temporal_finalize_dev(C.c_void_p(sx.data_ptr()), C.c_void_p(sxx.data_ptr()), C.c_void_p(mine.data_ptr()), rows * W,
+                                             C.c_void_p(maps[0].data_ptr()), C.c_void_p(maps[1].data_ptr()), C.c_void_p(maps[2].data_ptr()), st))
+    gathered = torch.empty((world, 3, rows * W), dtype=torch.float32, device=t.device)
+    if ev:
+        ev[2].record()
+    dist.all_gather_into_tensor(gathered.view(-1), maps.view(-1), group=group)
+    if ev:
+        ev[3].record()
+        ev[3].synchronize()
+        timings["reduce_scatter_ms"] = float(ev[0].elapsed_time(ev[1]))
+        timings["all_gather_ms"] = float(ev[2].elapsed_time(ev[3]))
+    full = gathered.permute(1, 0, 2).reshape(3, world * rows, W)[:, :H]
+    return full[0].contiguous(), full[1].contiguous(), full[2].contiguous()
+
+
 def temporal_stats(local_stack, *, group=None, chunk: int = 1024, overlap_chunks: int = 1, return_tensors: bool = False,
-                   timings: dict | None = None):
+                   timings: dict | None = None, collective: str = "all_reduce"):
     """mean / variance / contrast maps over ALL frames of all ranks.
 
     local_stack: this rank's frames (T_local, H, W), NumPy or ROCm tensor (float32 used; any H, W).
     overlap_chunks: row blocks whose all-reduce overlaps the accumulation of the following blocks (1 = one collective).
-    timings: optional dict receiving {"allreduce_ms": ...} (HIP events around the collective; forces a device sync).
+    collective: "all_reduce" (one all-reduce of the packed sums) or "reduce_scatter" (reduce-scatter of row slices, local
+        finalisation, all-gather of the float32 maps: module docstring); without a process group both are the local computation.
+    timings: optional dict receiving {"allreduce_ms": ...} or {"reduce_scatter_ms", "all_gather_ms"} (HIP events around the
+        collectives; forces a device sync).
     Returns (mean, var, contrast) float32 (H, W)."""
     torch = _ffi.require_gpu()
     from .. import _device as D
 
+    if collective not in ("all_reduce", "reduce_scatter"):
+        raise ValueError("collective must be 'all_reduce' or 'reduce_scatter'.")
     t, _, _ = D.to_device_f32(local_stack, ndim=(3,))
     T, H, W = (int(v) for v in t.shape)
     dist = _dist_group(group)
+    if dist is not None and collective == "reduce_scatter":
+        mean, var, con = _temporal_stats_scatter(torch, dist, group, t, chunk, timings)
+        if return_tensors:
+            return mean, var, con
+        return mean.cpu().numpy(), var.cpu().numpy(), con.cpu().numpy()
     acc = TemporalSums(H, W, t.device, overlap_chunks if dist is not None else 1)
     acc.add_count(T)
     mean = torch.empty((H, W), dtype=torch.float32, device=t.device)
@@ -142,6 +219,44 @@ def shard_bounds(total_frames: int, world_size: int, rank: int) -> tuple[int, in
     base, rem = divmod(int(total_frames), int(world_size))
     t0 = rank * base + min(rank, rem)
     return t0, t0 + base + (1 if rank < rem else 0)
+
+
+def scatter_reduce_sums_cpu(sum_x: np.ndarray, sum_xx: np.ndarray, count: int, finalize, group=None):
+    """The reduce-scatter + all-gather route on host arrays (gloo) for the multi-process CPU tests: same slice layout, same two
+    collectives as _temporal_stats_scatter; `finalize(sum_x, sum_xx, count)` -> (mean, var, con) stands in for the device kernel."""
+    import torch
+
+    dist = _dist_group(group)
+    H, W = sum_x.shape
+    world = dist.get_world_size(group) if dist is not None else 1
+    rank = dist.get_rank(group) if dist is not None else 0
+    rows, per = scatter_layout(H, W, world)
+    buf = torch.zeros((world, per), dtype=torch.float64)
+    buf[:, 0] = float(count)
+    for r in range(world):
+        r0, r1 = r * rows, min((r + 1) * rows, H)
+        if r1 > r0:
+            n = (r1 - r0) * W
+            buf[r, TemporalSums.HEAD:TemporalSums.HEAD + n] = torch.from_numpy(np.ascontiguousarray(sum_x[r0:r1], dtype=np.float64).ravel())
+            buf[r, TemporalSums.HEAD + rows * W:TemporalSums.HEAD + rows * W + n] = torch.from_numpy(
+                np.ascontiguousarray(sum_xx[r0:r1], dtype=np.float64).ravel())
+    mine = torch.empty(per, dtype=torch.float64)
+    if dist is not None:
+        _reduce_scatter(dist, mine, buf.view(-1), group)
+    else:
+        mine.copy_(buf[0])
+    m = mine.numpy()
+    with np.errstate(all="ignore"):
+        maps = finalize(m[TemporalSums.HEAD:TemporalSums.HEAD + rows * W].reshape(rows, W),
+                        m[TemporalSums.HEAD + rows * W:].reshape(rows, W), float(m[0]))
+    local = torch.from_numpy(np.stack([np.asarray(x, dtype=np.float32) for x in maps]).reshape(-1).copy())
+    gathered = torch.empty(world * local.numel(), dtype=torch.float32)
+    if dist is not None:
+        dist.all_gather_into_tensor(gathered, local, group=group)
+    else:
+        gathered.copy_(local)
+    full = gathered.view(world, 3, rows, W).permute(1, 0, 2, 3).reshape(3, world * rows, W)[:, :H].numpy()
+    return full[0].copy(), full[1].copy(), full[2].copy(), float(m[0])
 
 
 def reduce_sums_cpu(sum_x: np.ndarray, sum_xx: np.ndarray, count: int, group=None):

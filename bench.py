@@ -283,10 +283,26 @@ def secondary_cfg4(torch, dist, stack, world: int, rank: int, cpu: bool):
             dt = float(tmax.item())
         best = min(best, dt)
     bytes_frame = 4 * H * W
+    alt = None
+    if world > 1:      # SURVEY.md section 8e's all-links alternative beside the north-star's single all-reduce: reduce-scatter of row
+        ts = {}        # slices, local finalisation, all-gather of the float32 maps (same maps, bit for bit)
+        best_s = 1e30
+        for _ in range(3):
+            sync()
+            t0 = time.perf_counter()
+            temporal_stats(stack, return_tensors=True, collective="reduce_scatter", timings=ts)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            tmax = torch.tensor([dts], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            best_s = min(best_s, float(tmax.item()))
+        alt = {"frames_per_s": T * world / best_s, "reduce_scatter_ms": ts.get("reduce_scatter_ms"), "all_gather_ms": ts.get("all_gather_ms"),
+               "payload_bytes": {"reduce_scatter_in": 8 * world * (2 + 2 * (-(-H // world)) * W), "all_gather_out": 4 * 3 * world * (-(-H // world)) * W}}
     line = {"workload": f"cfg4: temporal mean/var/contrast, {T} frames of {H}x{W} per GPU x {world} GPU(s), "
                         + ("one RCCL all-reduce of 2*H*W+2 float64" if world > 1 else "no collective at N = 1"),
             "frames_per_s": T * world / best, "per_gpu": fractions(bytes_frame, bytes_frame, T / best),
-            "allreduce_ms": tm.get("allreduce_ms"), "allreduce_payload_bytes": 8 * (2 * H * W + 2) if world > 1 else 0}
+            "allreduce_ms": tm.get("allreduce_ms"), "allreduce_payload_bytes": 8 * (2 * H * W + 2) if world > 1 else 0,
+            "reduce_scatter_all_gather_route": alt}
     # correctness on a small stack that every rank can generate: N-rank sharded result == single-rank result, and both
     # against the float64 NumPy expressions (oracle/temporal_np.py)
     Ts = 8 * world + 3

@@ -33,7 +33,11 @@ def _worker(rank, world, port, total, out_dir):
     sx, sxx, n = Tn.temporal_sums(stack[t0:t1]) if t1 > t0 else (np.zeros((64, 64)), np.zeros((64, 64)), 0)
     gx, gxx, cnt = reduce_sums_cpu(sx, sxx, n)
     mean, var, con = Tn.finalize_sums(gx, gxx, cnt)
-    np.savez(os.path.join(out_dir, f"r{rank}.npz"), mean=mean, var=var, con=con, cnt=cnt)
+    # the reduce-scatter + all-gather route (row slices, one per rank; 64 rows do not divide by 3: the last slice is padded)
+    from barc4dip_amd.metrics.temporal import scatter_reduce_sums_cpu
+
+    smean, svar, scon, scnt = scatter_reduce_sums_cpu(sx, sxx, n, Tn.finalize_sums)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), mean=mean, var=var, con=con, cnt=cnt, smean=smean, svar=svar, scon=scon, scnt=scnt)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,6 +55,10 @@ def test_sharded_temporal_stats_equal_single_rank(tmp_path, world, total):
         np.testing.assert_allclose(g["mean"], rm, rtol=1e-14)
         np.testing.assert_allclose(g["var"], rv, rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(g["con"], rc, rtol=1e-9)
+        # same sums, same finalisation, float32 on the wire: the scatter route equals the all-reduce route rounded to float32
+        assert float(g["scnt"]) == total
+        for k in ("mean", "var", "con"):
+            assert np.array_equal(g["s" + k], g[k].astype(np.float32)), k
     a, b = np.load(tmp_path / "r0.npz"), np.load(tmp_path / f"r{world - 1}.npz")
     assert np.array_equal(a["mean"], b["mean"]) and np.array_equal(a["var"], b["var"])   # every rank holds the same bits
 

@@ -140,11 +140,17 @@ def test_temporal_stats_packed_allreduce_and_row_block_overlap():
         one = [x.cpu().numpy() for x in temporal_stats(stack, return_tensors=True, timings=tm)]
         assert "allreduce_ms" in tm and tm["allreduce_ms"] >= 0.0
         blocks = [x.cpu().numpy() for x in temporal_stats(stack, return_tensors=True, overlap_chunks=5, chunk=5)]
+        # SURVEY.md section 8e's alternative: reduce-scatter of row slices, local finalisation, all-gather of the float32 maps
+        ts = {}
+        scat = [x.cpu().numpy() for x in temporal_stats(stack, return_tensors=True, collective="reduce_scatter", timings=ts)]
+        assert ts["reduce_scatter_ms"] >= 0.0 and ts["all_gather_ms"] >= 0.0
+        with pytest.raises(ValueError):
+            temporal_stats(stack, collective="ring")
     finally:
         if created:
             dist.destroy_process_group()
-    for a, b, c in zip(plain, one, blocks):
-        assert np.array_equal(a, b) and np.array_equal(a, c)
+    for a, b, c, d in zip(plain, one, blocks, scat):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d, equal_nan=True)
 
 
 def test_reduction_entry_points_on_two_streams(K):
