@@ -104,7 +104,9 @@ int b4d_psd_autocorr2d_timed(b4d_plan* plan, const float* frames, int batch, flo
  * one), the fastest stays with the plan and the others are freed.  An allocation failure only ends the search.  Synchronises
  * `stream`; on return psd / autocorr hold the result of a normal call.  best_ms / worst_ms (optional) receive the time per
  * pass on the kept and on the slowest candidate.  All candidates are alive until the choice is made: up to
- * (candidates - 1) x b4d_plan_workspace_bytes of extra device memory for the duration of the call.                         */
+ * (candidates - 1) x b4d_plan_workspace_bytes of extra device memory for the duration of the call.
+ * A diagnostic since round 3: five consecutive processes on one box ran the untuned plan within 0.3 % of the tuned one
+ * (profiles/r03_placement.txt), and bench.py no longer calls it (only `--tune-compare K` does, after its timed region).        */
 int b4d_plan_tune(b4d_plan* plan, const float* frames, int batch, float* psd, float psd_scale, float* autocorr,
                   unsigned flags, int candidates, float* best_ms, float* worst_ms, void* stream);
 
