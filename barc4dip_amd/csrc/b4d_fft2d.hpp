@@ -77,9 +77,11 @@ template <bool WHITEN>
 __device__ __forceinline__ float2 cross_power(float2 a, float2 b, float eps) {
     float2 c = make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
     if (WHITEN) {
-        const float m = sqrtf(fmaf(c.x, c.x, c.y * c.y)) + eps;
-        c.x /= m;
-        c.y /= m;
+        // hardware square root and reciprocal (1 ulp each) and two multiplies: the IEEE sqrtf and the two divisions this replaces
+        // were ~35 of the ~70 vector instructions the cross-power column pass spends per element (half of k_col_prod's stream)
+        const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(c.x, c.x, c.y * c.y)) + eps);
+        c.x *= inv;
+        c.y *= inv;
     }
     return c;
 }
@@ -134,12 +136,13 @@ k_row_r2c(const float* __restrict__ in, float2* __restrict__ spec, float* __rest
             const bool ina = ya >= sd.y0 && ya < sd.y1, inb = yb >= sd.y0 && yb < sd.y1;
             const float* r0 = in + ((size_t)sd.frame * ny + ya) * NX;
             const float* r1 = r0 + NX;
+            const float inv = 1.0f / sd.denom;   // one division per item instead of 32 per lane (z-score: signal/tracking.py:308-311)
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 const int x = u + T * j;
                 const bool inx = x >= sd.x0 && x < sd.x1;
-                v[j].x = (ina && inx) ? (r0[x] - sd.mean) / sd.denom : 0.f;
-                v[j].y = (inb && inx) ? (r1[x] - sd.mean) / sd.denom : 0.f;
+                v[j].x = (ina && inx) ? (r0[x] - sd.mean) * inv : 0.f;
+                v[j].y = (inb && inx) ? (r1[x] - sd.mean) * inv : 0.f;
             }
         } else {
             const float* r0 = in + (frame * ny + 2 * (size_t)pair) * NX;

@@ -414,8 +414,9 @@ __global__ void __launch_bounds__(256) k_sat_rows(const float* __restrict__ fram
     const size_t W1 = (size_t)nx + 1, base = (size_t)blockIdx.y * (ny + 1) * W1;
     double a1 = 0.0, a2 = 0.0;
     const int x0 = threadIdx.x * per, x1 = min(nx, x0 + per);
+    const float inv = 1.0f / sd.denom;   // the same float32 z-score as k_row_r2c's (one division per item)
     for (int x = x0; x < x1; ++x) {
-        const double v = (double)((row[x] - sd.mean) / sd.denom);
+        const double v = (double)((row[x] - sd.mean) * inv);
         a1 += v;
         a2 = fma(v, v, a2);
     }
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(256) k_sat_rows(const float* __restrict__ fram
     double* o1 = sat1 + base + (size_t)(y + 1) * W1;
     double* o2 = sat2 + base + (size_t)(y + 1) * W1;
     for (int x = x0; x < x1; ++x) {
-        const double v = (double)((row[x] - sd.mean) / sd.denom);
+        const double v = (double)((row[x] - sd.mean) * inv);
         r1 += v;
         r2 = fma(v, v, r2);
         o1[x + 1] = r1;

@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(MY::LANES, 4) k_wmr_cols(float2* __restrict__ 
             if (MODE == 0) {
                 if (sep.y) {   // fv = {hy, ly} of this row: W = t / (t^2 + balance s^2), t = hx hy, s = lx + ly (real)
                     const float t = sx.x * fv[r][n1].x, sl = sx.y + fv[r][n1].y;
-                    const float wv = t / fmaf(t, t, sep.balance * sl * sl);
+                    const float wv = t * __builtin_amdgcn_rcpf(fmaf(t, t, sep.balance * sl * sl));   // hardware reciprocal (1 ulp): the pass is issue-bound
                     const float2 b = buf[pi.pos()];
                     v[r][n1] = make_float2(b.x * wv, -(b.y * wv));
                 } else {
