@@ -40,7 +40,7 @@ int spectrum_rows_last(const b4d_plan* pl, const float* frames, int batch, float
 
 extern "C" {
 
-const char* b4d_version(void) { return "b4d 0.2.0 (gfx950)" B4D_VERSION_SUFFIX; }
+const char* b4d_version(void) { return "b4d 0.3.0 (gfx950)" B4D_VERSION_SUFFIX; }
 const char* b4d_last_error(void) { return last_error().c_str(); }
 int b4d_set_option(const char* name, int value) {
     if (!name) return fail(B4D_EINVAL, "null option name");
