@@ -382,14 +382,18 @@ def speckle_stats(image: np.ndarray, *, metrics: str | Sequence[str] = "all", ti
         raise TypeError("speckle_stats expects a numpy.ndarray")
     if image.ndim != 2:
         raise ValueError(f"Expected 2D array, got ndim={image.ndim}")
-    image = apply_display_origin(image, display_origin=display_origin)
-    h, w = image.shape
+    from .common import normalize_display_origin
+
+    lower = normalize_display_origin(display_origin) == "lower"   # apply_display_origin (common.py:44-72): rows flipped before
+    h, w = image.shape                                            # the metrics -- on the device (a strided host copy costs 1 ms)
     groups = normalize_groups(metrics, all_groups=_ALL_SPECKLE_GROUPS, context="speckles", param_name="metrics")
     if verbose:
         logger.info("\nspeckle stats for a (h x w: %.0f x %.0f) image:", h, w)
     out: dict = {"meta": {"kind": "speckles", "display_origin": display_origin, "input_shape": (int(h), int(w)),
                           "requested_groups": sorted(groups), "units": _SPECKLE_UNITS}, "full": {}}
     t = _dev2d(np.ascontiguousarray(image))
+    if lower:
+        t = t.flip(0).contiguous()
     if "amplitude" in groups:
         out["full"]["amplitude"] = amplitude(t, verbose=verbose)
     if "grain" in groups:
