@@ -106,13 +106,20 @@ struct ProdArgs {
     const int* idx_b;
     float2* g;              // (pairs) tile-major output of the inverse column pass
     const float2* tw;
+    const float2* tw2;      // the same table through a second pointer (TPL: keeps the first transform's twiddles from staying live)
     float eps;
     int nt;
     unsigned flags;         // B4D_REMOVE_MEAN: zero the DC bin of the product (both means removed)
+    const RowSrc* srcs_b;   // TPL: item ib of spec_b holds ROW-transformed data in rows [y0, y1) only (k_row_r2c of a zero-embedded
+                            // ROI); its column transform happens here
 };
 
 // grid (nt, pairs), block ColCfg<NY>::THREADS (same tile geometry as k_col).
-template <int NY, bool WHITEN>
+// TPL (phase-correlation tracking): the template operand arrives row-transformed only, in its ROI rows (121 of 1024 in cfg3), and its
+// forward column transform runs here, in registers, ahead of the product -- the same Fft3 code on the same values as
+// k_col<COL_FORWARD>, i.e. bit-identical spectra, without writing a 4-MB half spectrum per template and reading it back per pair
+// (585 of the 649 spectra of a cfg3 call are templates, 576 of them used once).
+template <int NY, bool WHITEN, bool TPL = false>
 __global__ void __launch_bounds__(ColCfg<NY>::THREADS, ColCfg<NY>::WAVES_PER_EU) k_col_prod(ProdArgs p) {
     using Cfg = ColCfg<NY>;
     using G = typename Cfg::G;
@@ -127,21 +134,58 @@ __global__ void __launch_bounds__(ColCfg<NY>::THREADS, ColCfg<NY>::WAVES_PER_EU)
     float2* tg = p.g + ((pair * nt + ct) * (size_t)NY) * CT;
     const unsigned toff = (unsigned)u * CT + NC * cp;
     float2 v[NC][E];
+    if (TPL) {
+        const int ry0 = p.srcs_b[ib].y0, ry1 = p.srcs_b[ib].y1;
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
+        for (int j = 0; j < E; ++j) {
 #pragma unroll
-        for (int h = 0; h < NC / 2; ++h) {
-            const float4 qa = *reinterpret_cast<const float4*>(ta + (size_t)(T * j * CT) + toff + 2 * h);
-            const float4 qb = *reinterpret_cast<const float4*>(tb + (size_t)(T * j * CT) + toff + 2 * h);
-            float2 c0 = cross_power<WHITEN>(make_float2(qa.x, qa.y), make_float2(qb.x, qb.y), p.eps);
-            const float2 c1 = cross_power<WHITEN>(make_float2(qa.z, qa.w), make_float2(qb.z, qb.w), p.eps);
-            if (h == 0 && j == 0 && ct == 0 && cp == 0 && u == 0 && (p.flags & B4D_REMOVE_MEAN))
-                c0 = make_float2(0.f, 0.f);  // DC bin of the cross spectrum (both means removed)
-            v[2 * h][j] = make_float2(c0.y, c0.x);  // (im, re)-swapped: inverse transform with the forward code
-            v[2 * h + 1][j] = make_float2(c1.y, c1.x);
+            for (int h = 0; h < NC / 2; ++h) {   // clamped row + select: unconditional loads (as k_col<COL_FORWARD>)
+                const int ky = u + T * j, kc = min(max(ky, ry0), ry1 - 1);
+                float4 q = *reinterpret_cast<const float4*>(tb + (size_t)kc * CT + NC * cp + 2 * h);
+                if (ky < ry0 || ky >= ry1) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                v[2 * h][j] = make_float2(q.x, q.y);
+                v[2 * h + 1][j] = make_float2(q.z, q.w);
+            }
+        }
+        Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL, true, Cfg::SB>(v, u, cp, lds, p.tw);
+        // v[c][j] = Ft[ky = u + T j][column c]: the product with the image tile replaces it in place
+        int tid1 = threadIdx.x;   // lane position derived again: the first transform's index set need not stay live (cf. k_col)
+        asm volatile("" : "+v"(tid1));
+        const unsigned toff1 = (unsigned)(tid1 / CPT) * CT + NC * (tid1 % CPT);
+        __syncthreads();          // every lane is done reading the exchange buffer
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int h = 0; h < NC / 2; ++h) {
+                const float4 qa = *reinterpret_cast<const float4*>(ta + (size_t)(T * j * CT) + toff1 + 2 * h);
+                float2 c0 = cross_power<WHITEN>(make_float2(qa.x, qa.y), v[2 * h][j], p.eps);
+                const float2 c1 = cross_power<WHITEN>(make_float2(qa.z, qa.w), v[2 * h + 1][j], p.eps);
+                if (h == 0 && j == 0 && ct == 0 && tid1 == 0 && (p.flags & B4D_REMOVE_MEAN)) c0 = make_float2(0.f, 0.f);
+                v[2 * h][j] = make_float2(c0.y, c0.x);
+                v[2 * h + 1][j] = make_float2(c1.y, c1.x);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int h = 0; h < NC / 2; ++h) {
+                const float4 qa = *reinterpret_cast<const float4*>(ta + (size_t)(T * j * CT) + toff + 2 * h);
+                const float4 qb = *reinterpret_cast<const float4*>(tb + (size_t)(T * j * CT) + toff + 2 * h);
+                float2 c0 = cross_power<WHITEN>(make_float2(qa.x, qa.y), make_float2(qb.x, qb.y), p.eps);
+                const float2 c1 = cross_power<WHITEN>(make_float2(qa.z, qa.w), make_float2(qb.z, qb.w), p.eps);
+                if (h == 0 && j == 0 && ct == 0 && cp == 0 && u == 0 && (p.flags & B4D_REMOVE_MEAN))
+                    c0 = make_float2(0.f, 0.f);  // DC bin of the cross spectrum (both means removed)
+                v[2 * h][j] = make_float2(c0.y, c0.x);  // (im, re)-swapped: inverse transform with the forward code
+                v[2 * h + 1][j] = make_float2(c1.y, c1.x);
+            }
         }
     }
-    Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL, true, Cfg::SB>(v, u, cp, lds, p.tw);
+    {
+        int tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        Fft3<G, 1>::template run_sets<NC, Cfg::SERIAL, true, Cfg::SB>(v, tid2 / CPT, tid2 % CPT, lds, TPL ? p.tw2 : p.tw);
+    }
     unsigned toff2 = toff;   // laundered: the store addresses are not kept live across the transform (spills otherwise)
     asm volatile("" : "+v"(toff2));
 #pragma unroll
@@ -696,6 +740,13 @@ using namespace b4d;
 template <int NY, bool WHITEN>
 static int launch_prod(const ProdArgs& a, int nt, int pairs, hipStream_t st) {
     using Cfg = ColCfg<NY>;
+    if (WHITEN && a.srcs_b) {   // tracking: template column transforms fused in (TPL)
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_col_prod<NY, WHITEN, WHITEN>), Cfg::LDS_BYTES);
+        if (rc_lds) return rc_lds;
+        hipLaunchKernelGGL((k_col_prod<NY, WHITEN, WHITEN>), dim3(nt, pairs), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
+        B4D_HIP(hipGetLastError());
+        return B4D_OK;
+    }
     {
         const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_col_prod<NY, WHITEN>), Cfg::LDS_BYTES);
         if (rc_lds) return rc_lds;
@@ -721,8 +772,10 @@ static int dispatch_prod(const b4d_plan* pl, ProdArgs a, int pairs, hipStream_t 
 }
 
 // forward 2-D half spectra of `items` sources into spec (tile-major) + nyq (items, ny) complex
+// columns = false: the tiles stay row-transformed (ROI rows only) -- k_col_prod<.., TPL> transforms them per pair; the Nyquist
+// column is transformed either way
 static int forward_spectra(const b4d_plan* pl, const float* frames, const RowSrc* srcs, int items, float2* spec,
-                           float* nyq_rows, float2* nyq, hipStream_t st) {
+                           float* nyq_rows, float2* nyq, hipStream_t st, bool columns = true) {
     int rc = dispatch_r2c(pl, frames, items, st, spec, nyq_rows, srcs);
     if (rc) return rc;
     ColArgs ca{};
@@ -730,7 +783,7 @@ static int forward_spectra(const b4d_plan* pl, const float* frames, const RowSrc
     ca.tw = pl->tw_y;
     ca.nx = pl->nx;
     ca.srcs = srcs;    // zero-embedded ROIs: only the ROI rows exist in `spec` / `nyq_rows`
-    if ((rc = dispatch_col<COL_FORWARD>(pl, ca, items, st))) return rc;
+    if (columns && (rc = dispatch_col<COL_FORWARD>(pl, ca, items, st))) return rc;
     NyqArgs na{};
     na.rows = nyq_rows;
     na.f_out = nyq;
@@ -772,7 +825,7 @@ static int track_arena(b4d_plan* pl, size_t bytes, Arena* a) {
 template <bool WHITEN>
 static int product_inverse(const b4d_plan* pl, const float2* spec, const float2* nyq, const int* idx_a, const int* idx_b,
                            const float2* spec_b, const float2* nyq_b, int pairs, float2* g, float* gnyq, float eps,
-                           unsigned flags, hipStream_t st) {
+                           unsigned flags, hipStream_t st, const RowSrc* srcs_b = nullptr) {
     ProdArgs pa{};
     pa.spec_a = spec;
     pa.spec_b = spec_b;
@@ -780,6 +833,8 @@ static int product_inverse(const b4d_plan* pl, const float2* spec, const float2*
     pa.idx_b = idx_b;
     pa.g = g;
     pa.tw = pl->tw_y;
+    pa.tw2 = pl->tw_y;
+    pa.srcs_b = srcs_b;
     pa.eps = eps;
     pa.flags = flags;
     int rc = dispatch_prod<WHITEN>(pl, pa, pairs, st);
@@ -1096,14 +1151,14 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     for (int k0 = 0; k0 < ntpl; k0 += fc) {
         const int n = std::min(fc, ntpl - k0), o = nimg + k0;
         if ((rc = forward_spectra(pl, tpl_src, srcs + o, n, spec + half * o, nyq_rows + (size_t)ny * o,
-                                  nyq + (size_t)ny * o, st)))
+                                  nyq + (size_t)ny * o, st, /*columns=*/false)))   // transformed per pair in k_col_prod<.., TPL>
             return rc;
     }
     // ---- pairs
     for (int p0 = 0; p0 < npairs; p0 += pc) {
         const int np = std::min(pc, npairs - p0);
         if ((rc = product_inverse<true>(pl, spec, nyq, pidx + p0, pidx + npairs + p0, spec, nyq, np, g, gnyq, (float)eps,
-                                        0u, st)))
+                                        0u, st, srcs)))
             return rc;
         RowOutArgs ra{};
         ra.g = g;
