@@ -185,12 +185,13 @@ def secondary_cfg3(torch, cpu: bool):
     nh, hh = n // 2 + 1, n // 2
     model = 12 * n * n + 56 * n * nh
     # bytes this implementation moves per pair (profiles/*pmc_cfg3*): every image spectrum is built once and shared
-    # by its 18 pairs (row pass 4n^2 + 4n^2, column pass in place 4n^2 + 4n^2); a template spectrum is built once per (frame, ROI)
-    # from its `side` non-zero rows (row pass side^2*4 in, side*n/2*8 out; column pass reads those rows, writes the whole half
-    # spectrum) and serves the "abs" pairs of all frames or one "inc" pair; per pair the cross-power column pass reads two half
-    # spectra and writes one, the inverse row pass reads it and writes no map (arg-max, median bin and 3 rows only).
+    # by its 18 pairs (row pass 4n^2 + 4n^2, column pass in place 4n^2 + 4n^2); a template is row-transformed once per (frame, ROI)
+    # from its `side` non-zero rows (side^2*4 in, side*n/2*8 out) and serves the "abs" pairs of all frames or one "inc" pair; per
+    # pair the cross-power column pass reads the image's half spectrum and the template's `side` rows (its column transform
+    # happens in registers), writes one half spectrum, and the inverse row pass reads it and writes no map (arg-max, median bin
+    # and 3 rows only).
     ntpl = len(tpl_frame)
-    moved = (T * 16 * n * n + ntpl * (4 * side * side + 2 * 8 * side * hh + 8 * n * hh)) / npairs + 3 * 8 * n * hh + 8 * n * hh
+    moved = (T * 16 * n * n + ntpl * (4 * side * side + 8 * side * hh)) / npairs + 8 * n * hh + 8 * side * hh + 2 * 8 * n * hh
     line = {"workload": f"cfg3: phase-correlation tracking, {T} resident frames of {n}x{n}, 3x3 ROI grid abs + inc ({npairs} pairs)",
             "pairs_per_s": npairs / best, "frames_per_s": T / best, **fractions(model, moved, npairs / best),
             "ground_truth_recovered": truth}
