@@ -740,10 +740,10 @@ using namespace b4d;
 template <int NY, bool WHITEN>
 static int launch_prod(const ProdArgs& a, int nt, int pairs, hipStream_t st) {
     using Cfg = ColCfg<NY>;
-    if (WHITEN && a.srcs_b) {   // tracking: template column transforms fused in (TPL)
-        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_col_prod<NY, WHITEN, WHITEN>), Cfg::LDS_BYTES);
+    if (a.srcs_b) {   // tracking (phase correlation and NCC): template column transforms fused in (TPL)
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_col_prod<NY, WHITEN, true>), Cfg::LDS_BYTES);
         if (rc_lds) return rc_lds;
-        hipLaunchKernelGGL((k_col_prod<NY, WHITEN, WHITEN>), dim3(nt, pairs), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_col_prod<NY, WHITEN, true>), dim3(nt, pairs), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
         B4D_HIP(hipGetLastError());
         return B4D_OK;
     }
@@ -1324,13 +1324,14 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     }
     for (int k0 = 0; k0 < ntpl; k0 += fc) {
         const int n = std::min(fc, ntpl - k0), o = nimg + k0;
-        if ((rc = forward_spectra(pl, tpl_src, srcs + o, n, spec + half * o, nyq_rows + (size_t)ny * o, nyq + (size_t)ny * o, st)))
+        if ((rc = forward_spectra(pl, tpl_src, srcs + o, n, spec + half * o, nyq_rows + (size_t)ny * o, nyq + (size_t)ny * o, st,
+                                  /*columns=*/false)))   // transformed per pair in k_col_prod<.., TPL>
             return rc;
     }
     {
         for (int p0 = 0; p0 < npairs; p0 += pc) {
             const int np = std::min(pc, npairs - p0);
-            int r2 = product_inverse<false>(pl, spec, nyq, pidx + p0, sidx + p0, spec, nyq, np, g, gnyq, 0.f, 0u, st);
+            int r2 = product_inverse<false>(pl, spec, nyq, pidx + p0, sidx + p0, spec, nyq, np, g, gnyq, 0.f, 0u, st, srcs);
             if (r2) return r2;
             RowOutArgs ra{};
             ra.g = g;
