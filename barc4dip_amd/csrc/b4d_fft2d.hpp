@@ -72,6 +72,14 @@ __device__ __forceinline__ size_t spec_index(size_t frame, int nt, int ny, int c
     return ((frame * nt + (kx / ct_w)) * (size_t)ny + y) * ct_w + (kx % ct_w);
 }
 
+// the same index for power-of-two tile widths (16, or 8 at ny = 4096; always the case) with shifts and a 24-bit multiply: uniform
+// part (frame) in 64 bits, lane part in 32 bits (< ny nx / 2 <= 2^23)
+__device__ __forceinline__ size_t spec_index_pow2(size_t frame, int nt, int ny, int ct_w, int y, int kx) {
+    const int cs = __builtin_ctz(ct_w);
+    const unsigned lane = ((__umul24((unsigned)kx >> cs, (unsigned)ny) + (unsigned)y) << cs) + ((unsigned)kx & (unsigned)(ct_w - 1));
+    return ((frame * nt * (size_t)ny) << cs) + lane;
+}
+
 // c = a * conj(b), optionally whitened: c / (|c| + eps)   (signal/tracking.py:280-281)
 template <bool WHITEN>
 __device__ __forceinline__ float2 cross_power(float2 a, float2 b, float eps) {
@@ -664,7 +672,10 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
 #pragma unroll
     for (int j = 0; j < E / 2; ++j) {
         const int k = u + T * j;
-        const size_t o = spec_index(frame, nt, ny, ct_w, yl, k);
+        // C2R_MAG (issue-bound, profiles/r03_pmc_cfg3_sq.txt): the tile index without the integer division by the run-time tile width
+        // (a power of two) and with a 24-bit multiply -- the generic form costs ~40 quarter-rate multiplies per lane here.  The cfg2
+        // instantiation keeps spec_index: there the same change cost K3 1 % (instruction order).
+        const size_t o = MODE == C2R_MAG ? spec_index_pow2(frame, nt, ny, ct_w, yl, k) : spec_index(frame, nt, ny, ct_w, yl, k);
         // read once, written once: streaming hints on both sides of the row pass (-4 % on the cfg2 kernel)
         const f32x2 a_ = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.g + o)),
                     b_ = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.g + o + ct_w));
@@ -744,15 +755,33 @@ __global__ void __launch_bounds__((NX / E16) * SEQ) k_row_c2r(RowOutArgs p) {
                 o0[c] = m0;
                 o1[c] = m1;
             }
-            argmax_merge(bv, bi, m0, ra * NX + c);
-            argmax_merge(bv, bi, m1, rb * NX + c);
             if (pbx != 0xffffffffu) {
-                const unsigned b0 = m0 == m0 ? __float_as_uint(m0) >> 21 : 0xfffffffeu, b1 = m1 == m1 ? __float_as_uint(m1) >> 21 : 0xfffffffeu;
+                // a NaN magnitude has the key bits 0x3fe: above every bin a finite median can be expected in -- neither counted
+                // in the bin nor below it, without a select
+                const unsigned b0 = __float_as_uint(m0) >> 21, b1 = __float_as_uint(m1) >> 21;
                 hits |= (b0 == pbx ? 1u : 0u) << j | (b1 == pbx ? 1u : 0u) << (16 + j);
                 low += (b0 < pbx ? 1u : 0u) + (b1 < pbx ? 1u : 0u);
             }
         }
         cnt = __popc(hits);
+        // first-occurrence arg-max of the lane's 32 values: walked in ASCENDING flat index (row a before row b = row a + 1; inside a
+        // row the shifted column of register j is u + T ((j + E/2) % E)), so a strict `>` keeps the first of equal maxima and the
+        // index is rebuilt once from the winning slot -- three instructions per value instead of a (value, index) merge per value
+        float lv = -1.0f;
+        int ls = 0;
+#pragma unroll
+        for (int t = 0; t < 2 * E; ++t) {
+            const int j = ((t % E) + E / 2) % E;
+            const float m = fabsf((t < E ? v[j].y : v[j].x) * p.scale);
+            if (m > lv) {   // NaN never wins (as argmax_merge)
+                lv = m;
+                ls = t;
+            }
+        }
+        if (lv > -1.0f) {
+            bv = lv;
+            bi = (ls < E ? ra : rb) * NX + u + T * (ls % E);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
