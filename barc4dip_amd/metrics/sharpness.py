@@ -18,7 +18,7 @@ from .. import _ffi
 from ..signal import corr as _corr
 from ..signal import fft as _fft
 from . import kernels as K
-from .common import (apply_display_origin, choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
+from .common import (choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
                      tile_spans, tiled_scalar_fields, tiles_meta)
 from .speckles import (_dev2d, _fft_ok, _pad4, _pad_square_batch, _pad_square_dev, _tile_batches, _widths_batch, _widths_from_autocorr,
                        tiled_fields_batched, tiled_fields_batched_multi)

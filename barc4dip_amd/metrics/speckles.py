@@ -27,7 +27,7 @@ from ..signal import corr as _corr
 from ..signal import fft as _fft
 from ..signal.tracking import phase_correlation_batch, template_matching_batch
 from . import kernels as K
-from .common import (apply_display_origin, choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
+from .common import (choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
                      tile_spans, tiles_meta)
 from .statistics import moments_from_sums
 
