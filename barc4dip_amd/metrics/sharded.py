@@ -66,8 +66,24 @@ def track_abs_inc(dev, frame0, prev, rois, *, method: str = "phase", backend: st
     # per frame: 1 image + nroi inc-template half spectra (4 H W bytes each); the NCC matcher adds two float64 window-sum
     # tables per image (16 H W bytes = four more)
     blk = max(1, min(T, (budget // (4 * H * W) - nr) // (1 + nr + (4 if use_template else 0))))
-    if not use_template and backend != "internal":
-        raise ValueError("backend must be 'internal' for method='phase'.")
+    if not use_template and backend not in ("internal", "skimage"):
+        raise ValueError("backend must be 'internal' or 'skimage' for method='phase'.")
+    if not use_template and backend == "skimage":
+        # up-sampled phase cross-correlation (signal.tracking._phase_correlation_upsampled): device transforms, host refinement,
+        # one pair at a time -- the convenience route of that back-end, not a throughput path
+        from .. import _device as D
+        from ..signal.tracking import phase_correlation
+
+        f0h, prevh = D.to_host(frame0), D.to_host(prev)
+        ra, ri = np.empty((T * nr, 4)), np.empty((T * nr, 4))
+        for t in range(T):
+            cur = D.to_host(dev[t])
+            for k, (y0, y1, x0, x1) in enumerate(rois):
+                sl = (slice(int(y0), int(y1)), slice(int(x0), int(x1)))
+                ra[t * nr + k] = phase_correlation(f0h[sl], cur, slices_yx=sl, backend="skimage", subpixel=subpixel, eps=eps)
+                ri[t * nr + k] = phase_correlation(prevh[sl], cur, slices_yx=sl, backend="skimage", subpixel=subpixel, eps=eps)
+            prevh = cur
+        return ra, ri
     res_abs, res_inc = [], []
     for a in range(0, T, blk):
         b = min(T, a + blk)

@@ -448,9 +448,7 @@ def speckle_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "al
         if tracking_backend not in ("opencv", "skimage"):
             raise ValueError("backend must be 'opencv' or 'skimage'.")
     elif method == "phase":
-        if tracking_backend == "skimage":
-            raise ImportError("backend='skimage' requires scikit-image.")
-        if tracking_backend != "internal":
+        if tracking_backend not in ("internal", "skimage"):
             raise ValueError("backend must be 'internal' or 'skimage'.")
     else:
         raise ValueError(f"Unsupported tracking method: {tracking_method!r}. Supported: phase, template")
@@ -494,7 +492,7 @@ def speckle_stack_stats(stack: np.ndarray, *, metrics: str | Sequence[str] = "al
     from .sharded import track_abs_inc
 
     res_abs, res_inc = track_abs_inc(dev_all, dev_all[0], dev_all[0], rois, method=method,
-                                     backend=tracking_backend if method == "template" else "internal", subpixel=subpixel, eps=1e-9)
+                                     backend=tracking_backend, subpixel=subpixel, eps=1e-9)
     dy_abs = res_abs[:, 0].reshape(T, 3, 3).astype(np.float32)
     dx_abs = res_abs[:, 1].reshape(T, 3, 3).astype(np.float32)
     dy_inc = res_inc[:, 0].reshape(T, 3, 3).astype(np.float32)

@@ -14,6 +14,10 @@ normalised cross-correlation on the device (``b4d_template_match``): "opencv" z-
 the reference does before calling cv2, "skimage" passes the raw float32 image.  Parity with the two
 libraries is unpinned (they are absent from the build image); the oracle follows their published
 definition (oracle/ncc_np.py).
+
+``phase_correlation(backend="skimage")`` (tracking.py:262-272: skimage.registration.phase_cross_correlation with a ten-fold
+up-sampled peak search) is built from that function's published algorithm instead of raising ``ImportError``: device
+transforms, host refinement (``_phase_correlation_upsampled``; oracle/phase_skimage_np.py, parity unpinned).
 """
 from __future__ import annotations
 
@@ -189,6 +193,60 @@ def phase_correlation_batch(images, tpl_src, tpl_frame, tpl_roi, pair_img, pair_
     return (res, pij.cpu().numpy()) if return_peak_ij else res
 
 
+def _upsampled_dft(data: np.ndarray, region: int, upsample_factor: float, offsets) -> np.ndarray:
+    """Matrix-multiply DFT of `data` on `region` up-sampled points per axis from `offsets` (Guizar-Sicairos et al. 2008)."""
+    for n_items, off in list(zip(data.shape, offsets))[::-1]:
+        kernel = np.exp(-2j * np.pi * (np.arange(region) - off)[:, None] * np.fft.fftfreq(n_items, upsample_factor))
+        data = np.tensordot(kernel, data, axes=(1, -1))
+    return data
+
+
+def _phase_correlation_upsampled(tpl, img, slices_yx, subpixel: bool, eps: float):
+    """``backend="skimage"`` (tracking.py:262-272): the reference hands z-scored image and zero-embedded z-scored template to
+    ``skimage.registration.phase_cross_correlation(..., upsample_factor=10 if subpixel else 1)`` and returns its shift with
+    NaN for peak and snr.  Built here from that function's published algorithm (phase-normalised cross-power spectrum, coarse
+    peak, matrix-multiply DFT of a 1.5-pixel neighbourhood on a 0.1-px grid) so that the back-end works without scikit-image:
+    the two N x N transforms run on the device (``b4d_fft2d``); the cross-power spectrum, its inverse transform for the coarse
+    peak and the 15 x 15 up-sampled neighbourhood are host NumPy -- a per-call convenience path, not a throughput path.
+    Parity with scikit-image itself is unpinned (absent from the build image): the oracle is oracle/phase_skimage_np.py."""
+    from .fft import fft2d_stack
+
+    sy, sx = slices_yx
+    if D.is_tensor(img):
+        img = D.to_host(img)
+    if D.is_tensor(tpl):
+        tpl = D.to_host(tpl)
+    img = img if np.issubdtype(img.dtype, np.floating) else img.astype(np.float32)
+    tpl = tpl if np.issubdtype(tpl.dtype, np.floating) else tpl.astype(np.float32)
+    H, W = img.shape
+    img_z = (img - float(np.nanmean(img))) / (float(np.nanstd(img)) + eps)          # _zscore2d (tracking.py:308-311)
+    tpl_pad = np.zeros((H, W), dtype=np.float32)                                    # embed_roi(fill 0, float32) (roi.py:175-222)
+    tpl_pad[sy, sx] = (tpl - float(np.nanmean(tpl))) / (float(np.nanstd(tpl)) + eps)
+    F = fft2d_stack(np.stack([img_z.astype(np.float32), tpl_pad]))                  # fftshift-ed complex64 spectra from the device
+    F = np.fft.ifftshift(F, axes=(-2, -1)).astype(np.complex128)
+    prod = F[0] * np.conj(F[1])
+    prod /= np.maximum(np.abs(prod), 100 * np.finfo(np.float64).eps)               # normalization="phase"
+    cc = np.fft.ifft2(prod)
+    maxima = np.unravel_index(int(np.argmax(np.abs(cc))), cc.shape)
+    # the shift arithmetic runs in the precision the reference's call would use: float32 frames give complex64 spectra there,
+    # so its 0.1-px grid values are float32 numbers (3.3 comes back as 3.299999952316284)
+    ft = np.float32 if img_z.dtype == np.float32 else np.float64
+    shape = np.array([H, W])
+    shift = np.array(maxima, dtype=ft)
+    mid = np.fix(shape / 2)
+    shift[shift > mid] -= shape[shift > mid]
+    if subpixel:
+        uf = ft(10)
+        shift = np.round(shift * uf) / uf
+        region = np.ceil(uf * ft(1.5))
+        dftshift = np.fix(region / ft(2))
+        up = np.conj(_upsampled_dft(np.conj(prod), int(region), 10.0, (dftshift - shift * uf).astype(np.float64)))
+        m2 = np.unravel_index(int(np.argmax(np.abs(up))), up.shape)
+        shift = shift + (np.array(m2, dtype=ft) - dftshift) / uf
+    shift[shape == 1] = 0
+    return float(shift[0]), float(shift[1]), float("nan"), float("nan")
+
+
 @_register("phase")
 def phase_correlation(template, image, *, slices_yx=None, backend: Literal["internal", "skimage"] = "internal",
                       subpixel: bool = True, eps: float = 1e-9):
@@ -205,7 +263,7 @@ def phase_correlation(template, image, *, slices_yx=None, backend: Literal["inte
     if (sy.stop - sy.start, sx.stop - sx.start) != (h, w):
         raise ValueError("ROI shape does not match target slice dimensions.")
     if backend == "skimage":
-        raise ImportError("backend='skimage' requires scikit-image.")
+        return _phase_correlation_upsampled(tpl, img, (sy, sx), subpixel, eps)
     if backend != "internal":
         raise ValueError("backend must be 'internal' or 'skimage'.")
     timg, _, _ = D.to_device_f32(img[None], ndim=(3,))

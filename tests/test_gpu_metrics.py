@@ -134,8 +134,12 @@ def test_errors_match_reference(gm):
         gm.sharpness.spectral_entropy(np.where(img > 5000, np.nan, img))
     with pytest.raises(TypeError):
         gm.sharpness_stack_stats(img.tolist())
-    with pytest.raises(ImportError):
-        gm.speckle_stack_stats(img[None], tracking_method="phase", tracking_backend="skimage", verbose=False)
+    # phase + "skimage" needs scikit-image in the reference (ImportError without it); here the back-end is built in
+    out = gm.speckle_stack_stats(np.stack([img, np.roll(img, (2, -3), (0, 1))]), tracking_method="phase",
+                                 tracking_backend="skimage", roi_grain_factor=16.0, verbose=False)   # (3-grain ROIs are too
+    assert out["meta"]["tracking"]["backend"] == "skimage"                       # small for whitened correlation: oracle too)
+    assert out["meta"]["tracking"]["roi_size_yx"][0] >= 41
+    assert abs(out["temporal"]["abs"]["dy"][1] - 2) < 0.11 and abs(out["temporal"]["abs"]["dx"][1] + 3) < 0.11
     with pytest.raises(ValueError):
         gm.speckle_stack_stats(img[None], tracking_method="template", tracking_backend="internal", verbose=False)
     with pytest.warns(RuntimeWarning):

@@ -105,8 +105,12 @@ def test_dispatcher_errors_and_defaults(gs, golden):
         gs.track_translation(f0[sl], fr, method="template")            # backend "internal" invalid there
     r_t = gs.track_translation(f0[sl], fr, method="template", backend="skimage")   # NCC back-end runs on the device
     assert round(r_t[0]) == 3 and round(r_t[1]) == -5
-    with pytest.raises(ImportError):
-        gs.phase_correlation(f0[sl], fr, backend="skimage")
+    from oracle import phase_skimage_np as P
+
+    r_s = gs.phase_correlation(f0[sl], fr, backend="skimage")           # built from the published algorithm: no ImportError
+    w_s = P.phase_correlation_skimage(f0[sl], fr)
+    assert abs(r_s[0] - w_s[0]) < 1e-9 and abs(r_s[1] - w_s[1]) < 1e-9 and np.isnan(r_s[2]) and np.isnan(r_s[3])
+    assert round(r_s[0]) == 3 and round(r_s[1]) == -5                   # (shot noise: the 0.1-px estimate itself is 2.8, -4.8 ...)
     with pytest.raises(ValueError):
         gs.phase_correlation(f0[:120, :120], fr)                        # even template without slices
     with pytest.raises(ValueError):
@@ -440,3 +444,32 @@ def test_median_bin_prediction_is_only_a_route(gs):
             assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
     assert lib.b4d_set_option(b"no_such_option", 1) != 0
     assert np.all(np.rint(out[1][0][0][:8, 0]).reshape(4, 2) == sh[:, 0:1])
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (200, 300), (512, 1024)])
+def test_phase_correlation_skimage_backend_vs_oracle(gs, shape):
+    """``backend="skimage"`` (tracking.py:262-272): device transforms + host refinement on the 0.1-px grid against the float64
+    restatement of skimage.registration.phase_cross_correlation (oracle/phase_skimage_np.py; parity with scikit-image itself is
+    unpinned).  The shift is a multiple of 0.1 px: equal to the oracle's, peak and snr NaN like the reference."""
+    from oracle import phase_skimage_np as P
+
+    H, W = shape
+    base = synth_frame(max(H, W), 9)[:H, :W].astype(np.float64)
+    ky, kx = np.fft.fftfreq(H)[:, None], np.fft.fftfreq(W)[None, :]
+    for (dy, dx), (h, w) in (((3.3, -5.7), (121, 121)), ((-7.5, 11.25), (61, 81)), ((0.0, 0.0), (91, 91))):
+        fr = np.real(np.fft.ifft2(np.fft.fft2(base) * np.exp(-2j * np.pi * (ky * dy + kx * dx)))).astype(np.float32)
+        y0, x0 = (H - h) // 2 - 6, (W - w) // 2 + 9
+        sl = (slice(y0, y0 + h), slice(x0, x0 + w))
+        tpl = base[sl].astype(np.float32)
+        for sub in (True, False):
+            got = gs.phase_correlation(tpl, fr, slices_yx=sl, backend="skimage", subpixel=sub)
+            want = P.phase_correlation_skimage(tpl, fr, slices_yx=sl, subpixel=sub)
+            assert np.isnan(got[2]) and np.isnan(got[3])
+            assert abs(got[0] - want[0]) < 1e-9 and abs(got[1] - want[1]) < 1e-9, (shape, (dy, dx), sub, got, want)
+            assert abs(got[0] - dy) <= (0.15 if sub else 0.5) and abs(got[1] - dx) <= (0.15 if sub else 0.5)
+    # the dispatcher reaches the same route; float64 frames keep float64 grid values (the reference's complex128 branch)
+    via = gs.track_translation(tpl, fr, slices_yx=sl, method="phase", backend="skimage", subpixel=False)
+    assert via[:2] == got[:2]
+    g64 = gs.phase_correlation(tpl.astype(np.float64), fr.astype(np.float64), slices_yx=sl, backend="skimage")
+    w64 = P.phase_correlation_skimage(tpl.astype(np.float64), fr.astype(np.float64), slices_yx=sl)
+    assert g64[:2] == w64[:2]
