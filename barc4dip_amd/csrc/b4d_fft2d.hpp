@@ -885,6 +885,29 @@ struct b4d_plan {
     // both sides have in-register three-radix kernels (b4d_wiener_mr.hip): the transform-based entry points take those passes,
     // whatever the size class (228-px aggregator tiles as well as 2560 x 2160 frames); tw_x / tw_y are built for it
     bool wmr = false;
+    // second stream of the two-lane drivers (Lanes below; fork / join by events, created on first use)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
+// Two-lane launch groups (b4d_kernels.hip).  A multi-pass transform whose intermediate is written and read once runs faster in
+// groups whose workspace is about 64 MiB -- it stays in the 256-MB memory-side cache -- and with the groups dealt alternately to
+// the caller's stream and a second one, so that the passes of one group run under those of the other (no drained chip between
+// two launches, transform phases of one kernel under the memory phases of another).  Measured, frames/s (tools/dev_fft2d_chunk.py,
+// tools/dev_pipe_chunk.py): fft2d 2048^2 61.7 k in 64-frame groups, 61.8 k in 4-frame groups, 66.5-67.7 k in 4-frame groups on two
+// lanes; 1024^2 268 -> 277 k; 2160 x 2560 28.0 -> 31.4 k; psd + autocorr 2160 x 2560 20.0 -> 22.4 k, 1080 x 1920 55 -> 62.8 k,
+// 228^2 1.72 -> 1.91 M.  (The power-of-two psd + autocorr pipeline gains 1 % at 2048^2 and keeps its single large groups.)
+struct Lanes {
+    b4d_plan* pl = nullptr;
+    hipStream_t st = nullptr;
+    bool two = false;
+    int sub = 1;   // frames per group; lane l works in slot l of the workspaces (slot stride: `sub` frames)
+    // inter_bytes: intermediate bytes per frame; two lanes need 2 * sub <= chunk and groups of at least min_group_bytes of input
+    // (below that the launches themselves are what a group costs: 256^2 frames in two lanes of 64, 2.3 against 2.9 M frames/s)
+    int open(b4d_plan* p, hipStream_t s, int batch, size_t inter_bytes, size_t frame_bytes, bool allow_two, size_t min_group_bytes);
+    hipStream_t stream(int g) const { return two && (g & 1) ? pl->aux : st; }
+    int slot(int g) const { return two ? (g & 1) : 0; }
+    int close();   // joins the second lane into the caller's stream
 };
 
 // b4d_general.hip

@@ -327,15 +327,21 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
         // both sides have in-register three-radix kernels (b4d_wiener_mr.hip): forward row pairs -> transposed half spectra,
         // one pass over the columns (forward, |F|^2, inverse; the column stays in LDS), inverse row pairs + PSD rows:
         // 3 passes and ~32 bytes per pixel where the route below makes 7 passes
-        for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
-            const int nb = std::min(pl->chunk, batch - b0);
-            const size_t off = (size_t)b0 * npix;
-            int rc = wmr_psd_autocorr(frames + off, nb, ny, nx, pl->tw_x, pl->tw_y, pl->gbuf1, reinterpret_cast<float*>(pl->gbuf2),
-                                      reinterpret_cast<float*>(pl->gbuf3), psd ? psd + off : nullptr, psd_scale,
-                                      autocorr ? autocorr + off : nullptr, flags, st);
-            if (rc) return rc;
+        // two-lane launch groups (Lanes, b4d_fft2d.hpp): lane l works in slot l (sub frames of ny nx complex words) of each buffer
+        Lanes ln;
+        int rc = ln.open(pl, st, batch, wmr_spectrum_elems(ny, nx) * sizeof(float2), (size_t)npix * sizeof(float),
+                         wmr_spectrum_elems(ny, nx) <= (size_t)npix, (size_t)8 << 20);   // a slot holds the transposed half spectra of its frames
+        if (rc) return rc;
+        int g = 0;
+        for (int b0 = 0; b0 < batch && rc == B4D_OK; b0 += ln.sub, ++g) {
+            const int nb = std::min(ln.sub, batch - b0);
+            const size_t off = (size_t)b0 * npix, so = (size_t)ln.slot(g) * ln.sub * npix;
+            rc = wmr_psd_autocorr(frames + off, nb, ny, nx, pl->tw_x, pl->tw_y, pl->gbuf1 + so, reinterpret_cast<float*>(pl->gbuf2 + so),
+                                  reinterpret_cast<float*>(pl->gbuf3 + so), psd ? psd + off : nullptr, psd_scale,
+                                  autocorr ? autocorr + off : nullptr, flags, ln.stream(g));
         }
-        return B4D_OK;
+        const int rj = ln.close();
+        return rc ? rc : rj;
     }
     if (pl->large && pm_fusable(nx) && pm_fusable(ny)) {
         // half-spectrum path: pair rows -> transpose -> columns on nx/2 + 1 sequences -> |F|^2 (+ PSD) -> inverse columns ->
@@ -385,14 +391,20 @@ int general_psd_autocorr(b4d_plan* pl, const float* frames, int batch, float* ps
 int general_fft2d(b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st) {
     const int ny = pl->ny, nx = pl->nx, npix = ny * nx;
     if (pl->wmr) {   // mixed-radix kernels on both sides (b4d_wiener_mr.hip)
+        // two-lane launch groups (Lanes, b4d_fft2d.hpp): lane l works in gbuf(1 + l)
         const size_t selems = wmr_spectrum_elems(ny, nx);
-        for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
-            const int nb = std::min(pl->chunk, batch - b0);
-            int rc = wmr_fft2d(frames + (size_t)b0 * npix, nb, ny, nx, pl->tw_x, pl->tw_y, pl->gbuf1,
-                               reinterpret_cast<float*>(pl->gbuf1 + selems * nb), out + (size_t)b0 * npix, st);
-            if (rc) return rc;
+        Lanes ln;
+        int rc = ln.open(pl, st, batch, selems * sizeof(float2), (size_t)npix * sizeof(float), true, (size_t)8 << 20);   // (lane 1 has a buffer of its own)
+        if (rc) return rc;
+        int g = 0;
+        for (int b0 = 0; b0 < batch && rc == B4D_OK; b0 += ln.sub, ++g) {
+            const int nb = std::min(ln.sub, batch - b0);
+            float2* T = ln.slot(g) ? pl->gbuf2 : pl->gbuf1;
+            rc = wmr_fft2d(frames + (size_t)b0 * npix, nb, ny, nx, pl->tw_x, pl->tw_y, T, reinterpret_cast<float*>(T + selems * nb),
+                           out + (size_t)b0 * npix, ln.stream(g));
         }
-        return B4D_OK;
+        const int rj = ln.close();
+        return rc ? rc : rj;
     }
     for (int b0 = 0; b0 < batch; b0 += pl->chunk) {
         const int nb = std::min(pl->chunk, batch - b0);

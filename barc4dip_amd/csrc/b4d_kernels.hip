@@ -35,7 +35,40 @@ int ensure_dynamic_lds(const void* kernel, size_t bytes) {
 std::atomic<int> g_opt_track_predict{1};
 std::atomic<int> g_opt_exp{0};
 // b4d_spectrum.hip
-int spectrum_rows_last(const b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st);
+int spectrum_rows_last(const b4d_plan* pl, float2* spec, const float* frames, int batch, float2* out, hipStream_t st);
+}  // namespace b4d
+
+int Lanes::open(b4d_plan* p, hipStream_t s, int batch, size_t inter_bytes, size_t frame_bytes, bool allow_two, size_t min_group_bytes) {
+    pl = p;
+    st = s;
+    const int want = (int)std::max<size_t>(1, ((size_t)64 << 20) / std::max<size_t>(1, inter_bytes));
+    // two lanes need two slots of the workspaces and enough work to pay for the fork / join (a few microseconds of host time)
+    two = allow_two && batch >= 2 && p->chunk >= 2 && (size_t)batch * frame_bytes >= 2 * min_group_bytes &&
+          (size_t)std::min(want, p->chunk / 2) * frame_bytes >= min_group_bytes;
+    sub = two ? std::min(want, p->chunk / 2) : p->chunk;   // one lane: the plan's own groups
+    if (two) {   // an even number of groups of equal size
+        int groups = (batch + sub - 1) / sub;
+        groups += groups & 1;
+        sub = (batch + groups - 1) / groups;
+        if (!p->aux) {
+            B4D_HIP(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+            B4D_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            B4D_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        }
+        B4D_HIP(hipEventRecord(p->ev_fork, st));
+        B4D_HIP(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
+    }
+    return B4D_OK;
+}
+
+int Lanes::close() {
+    if (!two) return B4D_OK;
+    B4D_HIP(hipEventRecord(pl->ev_join, pl->aux));
+    B4D_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));
+    return B4D_OK;
+}
+
+namespace b4d {
 }  // namespace b4d
 
 extern "C" {
@@ -153,6 +186,12 @@ int b4d_plan_destroy(b4d_plan* p) {
     if (p->nyq_rows) (void)hipFree(p->nyq_rows);
     if (p->gnyq) (void)hipFree(p->gnyq);
     if (p->track_ws) (void)hipFree(p->track_ws);
+    if (p->aux) {
+        (void)hipStreamSynchronize(p->aux);
+        (void)hipStreamDestroy(p->aux);
+    }
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     for (float2* q : {p->wx, p->wy, p->gbuf1, p->gbuf2, p->gbuf3})
         if (q) (void)hipFree(q);
     delete p;
@@ -341,13 +380,20 @@ int b4d_fft2d(b4d_plan* pl, const float* frames, int batch, float* out_c64, void
     B4D_PLAN_LOCK(pl);
     hipStream_t st = (hipStream_t)stream;
     if (pl->general) return general_fft2d(pl, frames, batch, reinterpret_cast<float2*>(out_c64), st);
-    const size_t fpix = (size_t)pl->ny * pl->nx;
-    for (int b0 = 0; b0 < batch; b0 += pl->chunk) {   // columns first, rows last (b4d_spectrum.hip): every store of the full
-        const int nb = std::min(pl->chunk, batch - b0);   // spectrum is a whole line
-        int rc = spectrum_rows_last(pl, frames + b0 * fpix, nb, reinterpret_cast<float2*>(out_c64) + b0 * fpix, st);
-        if (rc) return rc;
-    }
-    return B4D_OK;
+    // Columns first, rows last (b4d_spectrum.hip): every store of the full spectrum is a whole line.  The half spectrum between the
+    // two passes (4 B / pixel, written and read once) stays in the memory-side cache: two-lane launch groups (Lanes); a 4096^2
+    // frame is a group of its own and stays on one lane (12.0 -> 13.8 k frames/s; 13.1 k on two).
+    const size_t fpix = (size_t)pl->ny * pl->nx, half = fpix / 2;
+    Lanes ln;
+    int rc = ln.open(pl, st, batch, half * sizeof(float2), fpix * sizeof(float), fpix < (size_t)4096 * 4096, (size_t)32 << 20);
+    if (!ln.two && fpix == (size_t)4096 * 4096) ln.sub = 1;
+    if (rc) return rc;
+    int g = 0;
+    for (int b0 = 0; b0 < batch && rc == B4D_OK; b0 += ln.sub, ++g)
+        rc = spectrum_rows_last(pl, pl->spec + (size_t)ln.slot(g) * ln.sub * half, frames + b0 * fpix, std::min(ln.sub, batch - b0),
+                                reinterpret_cast<float2*>(out_c64) + b0 * fpix, ln.stream(g));
+    const int rj = ln.close();
+    return rc ? rc : rj;
 }
 
 int b4d_fft2d_c2c(b4d_plan* pl, const float* in_c64, int batch, int inverse, float* out_c64, void* stream) {

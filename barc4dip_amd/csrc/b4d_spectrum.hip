@@ -103,7 +103,7 @@ k_col_r2c(const float* __restrict__ frames, float2* __restrict__ half, const flo
 
 // ------------------------------------------------------------------------------------ B
 // grid (ny / 2 / SEQ, batch); block (NX / 16) * SEQ.  BLK = column-order period of `half` (see half_pos).
-template <int NX, int SEQ, int BLK>
+template <int NX, int SEQ, int BLK, bool NTL = true>
 __global__ void __launch_bounds__((NX / E16) * SEQ)
 k_row_full(const float2* __restrict__ half, float2* __restrict__ out, const float2* __restrict__ tw, int ny) {
     using G = RowGeom<NX>;
@@ -118,7 +118,8 @@ k_row_full(const float2* __restrict__ half, float2* __restrict__ out, const floa
     float2 v[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const f32x2 q = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(src + half_pos<BLK>(u + T * j)));
+        const f32x2* qp = reinterpret_cast<const f32x2*>(src + half_pos<BLK>(u + T * j));
+        const f32x2 q = NTL ? __builtin_nontemporal_load(qp) : *qp;
         v[j] = make_float2(q.x, q.y);
     }
     Fft3<G, 1, WV>::run(v, v, u, 0, lds, tw);
@@ -164,17 +165,19 @@ static int launch_row_full(const float2* half, float2* out, const float2* tw, in
     const dim3 grid(ny / 2 / SEQ, batch), block((NX / E16) * SEQ);
     // measured and not kept (tools/dev_fft2d_var.py, interleaved): cached instead of streaming loads -2 %; 16-byte stores with
     // both rows re-read from the exchange buffer +-0 (the pass runs at 5.5 TB/s either way)
+    // the half spectrum is read from the memory-side cache (b4d_fft2d's launch groups): cached loads there, +1.5 % at 1024^2 and
+    // 2048^2; streaming loads stay for the 4096-row layout, whose single-frame groups leave the cache between the passes
     if (col_r2c_blk(ny) == 16)
-        hipLaunchKernelGGL((k_row_full<NX, SEQ, 16>), grid, block, 0, st, half, out, tw, ny);
+        hipLaunchKernelGGL((k_row_full<NX, SEQ, 16, true>), grid, block, 0, st, half, out, tw, ny);
     else
-        hipLaunchKernelGGL((k_row_full<NX, SEQ, 32>), grid, block, 0, st, half, out, tw, ny);
+        hipLaunchKernelGGL((k_row_full<NX, SEQ, 32, false>), grid, block, 0, st, half, out, tw, ny);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
 }
 
-int spectrum_rows_last(const b4d_plan* pl, const float* frames, int batch, float2* out, hipStream_t st) {
+int spectrum_rows_last(const b4d_plan* pl, float2* spec, const float* frames, int batch, float2* out, hipStream_t st) {
     int rc = B4D_ESIZE;
-#define B4D_CALL(N) launch_col_r2c<N>(frames, pl->spec, pl->tw_y, pl->nx, batch, st)
+#define B4D_CALL(N) launch_col_r2c<N>(frames, spec, pl->tw_y, pl->nx, batch, st)
     switch (pl->ny) {
         case 64: rc = B4D_CALL(64); break;
         case 128: rc = B4D_CALL(128); break;
@@ -186,7 +189,7 @@ int spectrum_rows_last(const b4d_plan* pl, const float* frames, int batch, float
     }
 #undef B4D_CALL
     if (rc != B4D_OK) return rc == B4D_ESIZE ? fail(B4D_ESIZE, "unsupported ny") : rc;
-#define B4D_CALL(N) launch_row_full<N>(pl->spec, out, pl->tw_x, pl->ny, batch, st)
+#define B4D_CALL(N) launch_row_full<N>(spec, out, pl->tw_x, pl->ny, batch, st)
     B4D_SIZE_SWITCH(pl->nx, B4D_CALL)
 #undef B4D_CALL
     return fail(B4D_ESIZE, "unsupported nx");
