@@ -885,7 +885,7 @@ struct b4d_plan {
     // both sides have in-register three-radix kernels (b4d_wiener_mr.hip): the transform-based entry points take those passes,
     // whatever the size class (228-px aggregator tiles as well as 2560 x 2160 frames); tw_x / tw_y are built for it
     bool wmr = false;
-    // second stream of the two-lane drivers (Lanes below; fork / join by events, created on first use)
+    // second stream of the two-lane drivers (Lanes below; the library's shared lane_stream(0); fork / join by this plan's events)
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };

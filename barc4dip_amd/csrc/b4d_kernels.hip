@@ -32,6 +32,28 @@ int ensure_dynamic_lds(const void* kernel, size_t bytes) {
     done.push_back(Done{kernel, dev, bytes});
     return B4D_OK;
 }
+int lane_stream(int idx, hipStream_t* out) {
+    static std::mutex mu;
+    struct Made {
+        int dev, idx;
+        hipStream_t st;
+    };
+    static std::vector<Made> made;
+    if (idx < 0 || idx > 1) return fail(B4D_EINVAL, "lane_stream: idx");
+    int dev = 0;
+    B4D_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Made& m : made)
+        if (m.dev == dev && m.idx == idx) {
+            *out = m.st;
+            return B4D_OK;
+        }
+    hipStream_t st = nullptr;
+    B4D_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    made.push_back(Made{dev, idx, st});
+    *out = st;
+    return B4D_OK;
+}
 std::atomic<int> g_opt_track_predict{1};
 std::atomic<int> g_opt_exp{0};
 // b4d_spectrum.hip
@@ -51,7 +73,8 @@ int Lanes::open(b4d_plan* p, hipStream_t s, int batch, size_t inter_bytes, size_
         groups += groups & 1;
         sub = (batch + groups - 1) / groups;
         if (!p->aux) {
-            B4D_HIP(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+            const int rs = b4d::lane_stream(0, &p->aux);
+            if (rs) return rs;
             B4D_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
             B4D_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
@@ -186,10 +209,7 @@ int b4d_plan_destroy(b4d_plan* p) {
     if (p->nyq_rows) (void)hipFree(p->nyq_rows);
     if (p->gnyq) (void)hipFree(p->gnyq);
     if (p->track_ws) (void)hipFree(p->track_ws);
-    if (p->aux) {
-        (void)hipStreamSynchronize(p->aux);
-        (void)hipStreamDestroy(p->aux);
-    }
+    if (p->aux) (void)hipStreamSynchronize(p->aux);   // the library's shared lane stream: not destroyed with the plan
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     for (float2* q : {p->wx, p->wy, p->gbuf1, p->gbuf2, p->gbuf3})

@@ -796,22 +796,28 @@ struct b4d_wiener {
     float mr_balance = 0.f;
     float2* mr_T = nullptr;      // (mr_cap, Wh, Hp) transposed half spectra of the frames of one launch
     float* mr_amax = nullptr;    // (mr_cap * (hp + 1)): max|frame| per frame, then the pair maxima
-    int mr_cap = 0;
+    int mr_cap = 0, mr_slots = 0;   // frames per slot, slots (one per lane of wiener_mr_apply)
+    static constexpr int MR_LANES = 2;
+    hipStream_t mr_aux[MR_LANES] = {};      // lane 1: the library's shared lane_stream(0) (lane 0 is the caller's stream)
+    hipEvent_t mr_fork = nullptr, mr_join[MR_LANES] = {};
 };
 
-// frames per launch of the mixed-radix route: the persistent row kernels hand 513 quads per 4k frame to 256 workgroups
+// frames per launch of the mixed-radix route on ONE lane: the persistent row kernels hand 513 quads per 4k frame to 256 workgroups
 // (2.004 rounds), so a launch needs several frames to amortise its last, nearly empty round (measured on MI355X,
-// 4096^2: 1 frame per launch 5.6 k frames/s, 4: 6.8 k, 8: 7.15 k, 16: 7.2 k); 68 MB of workspace per frame
+// 4096^2: 1 frame per launch 5.6 k frames/s, 4: 6.8 k, 8: 7.15 k, 16: 7.2 k); 68 MB of workspace per frame.  On two lanes
+// (wiener_mr_apply) the other lane's kernels fill that round and ONE frame per group (64 MiB of workspace) is best: it stays in the
+// memory-side cache between the passes (same box, 64 x 4096^2: one lane x 8 frames 7.65-7.78 k frames/s; two lanes x 8: 7.9-8.1 k,
+// x 4: 8.1 k, x 2: 7.8-8.0 k, x 1: 8.1-8.4 k; three lanes x 1: 7.4-7.6 k, four: 6.9 k)
 #ifndef B4D_WIENER_FPL
 #define B4D_WIENER_FPL 8
 #endif
-static int wiener_fpl() {
+static int wiener_fpl(bool lanes, size_t t_bytes) {   // t_bytes: transposed half spectrum of one frame
     static const int v = [] {
         const char* e = getenv("B4D_WIENER_FPL");   // tuning aid (tools/dev_cfg5.py); results do not depend on it
         const int n = e ? atoi(e) : 0;
-        return n >= 1 && n <= 64 ? n : B4D_WIENER_FPL;
+        return n >= 1 && n <= 64 ? n : 0;
     }();
-    return v;
+    return v ? v : lanes ? (int)std::min<size_t>(64, std::max<size_t>(1, ((size_t)64 << 20) / t_bytes)) : B4D_WIENER_FPL;
 }
 
 static void split_pm(int n, int* P, int* M) {
@@ -1111,10 +1117,15 @@ int b4d_wiener_destroy(b4d_wiener* p) {
         if (l > 0)
             for (void* q : {(void*)L.a, (void*)L.b, (void*)L.c, (void*)L.padded, (void*)L.amax})
                 if (q) (void)hipFree(q);
-        if (L.st) (void)hipStreamDestroy(L.st);
+        if (L.st) (void)hipStreamSynchronize(L.st);   // shared lane_stream(l): not destroyed with the plan
         if (L.done) (void)hipEventDestroy(L.done);
     }
     if (p->fork) (void)hipEventDestroy(p->fork);
+    for (int l = 1; l < b4d_wiener::MR_LANES; ++l) {
+        if (p->mr_aux[l]) (void)hipStreamSynchronize(p->mr_aux[l]);
+        if (p->mr_join[l]) (void)hipEventDestroy(p->mr_join[l]);
+    }
+    if (p->mr_fork) (void)hipEventDestroy(p->mr_fork);
     delete p;
     return B4D_OK;
 }
@@ -1265,33 +1276,63 @@ int b4d_wiener_create(int h, int w, const float* psf_host, int ky, int kx, float
     return B4D_OK;
 }
 
-// frames [0, batch) through the three kernels of b4d_wiener_mr.hip, B4D_WIENER_FPL frames per launch, all on `st`
+// frames [0, batch) through the three kernels of b4d_wiener_mr.hip, B4D_WIENER_FPL frames per launch; the launch groups are
+// dealt alternately to `st` and a second stream, each with its own slot of the workspace (two lanes: the passes of one group run
+// under those of the other)
 static int wiener_mr_apply(b4d_wiener* p, const float* frames, int batch, float* out, int clip, hipStream_t st) {
     WmrGeom g = p->geom;
     g.clip = clip;
-    const int fpl = std::min(batch, wiener_fpl());
-    if (fpl > p->mr_cap) {   // work queued earlier on other streams may still use the old buffers: drain before freeing
+    static const int lanes_env = [] {
+        const char* e = getenv("B4D_WIENER_LANES2");   // tuning aid (tools/dev_cfg5.py); results do not depend on it
+        const int n = e ? atoi(e) : 2;
+        return n >= 1 && n <= b4d_wiener::MR_LANES ? n : 2;
+    }();
+    const int nl = std::min(lanes_env, batch);
+    int fpl = std::min(batch, wiener_fpl(nl > 1, sizeof(float2) * (size_t)g.Wh * g.Hp));
+    if (nl > 1) fpl = std::min(fpl, (batch + nl - 1) / nl);
+    if (fpl > p->mr_cap || nl > p->mr_slots) {   // work queued earlier on other streams may still use the old buffers: drain before freeing
+        const int cap = std::max(fpl, p->mr_cap), slots = std::max(nl, p->mr_slots);
         B4D_HIP(hipDeviceSynchronize());
         for (void* q : {(void*)p->mr_T, (void*)p->mr_amax})
             if (q) (void)hipFree(q);
         p->mr_T = nullptr;
         p->mr_amax = nullptr;
-        p->mr_cap = 0;
-        hipError_t e = hipMalloc((void**)&p->mr_T, sizeof(float2) * (size_t)fpl * g.Wh * g.Hp);
-        if (e == hipSuccess) e = hipMalloc((void**)&p->mr_amax, sizeof(float) * (size_t)fpl * (g.hp + 1));
+        p->mr_cap = p->mr_slots = 0;
+        hipError_t e = hipMalloc((void**)&p->mr_T, sizeof(float2) * (size_t)slots * cap * g.Wh * g.Hp);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->mr_amax, sizeof(float) * (size_t)slots * cap * (g.hp + 1));
         if (e != hipSuccess) return fail(B4D_ENOMEM, std::string("wiener workspace: ") + hipGetErrorString(e));
-        p->mr_cap = fpl;
+        p->mr_cap = cap;
+        p->mr_slots = slots;
+    }
+    if (nl > 1) {
+        if (!p->mr_fork) B4D_HIP(hipEventCreateWithFlags(&p->mr_fork, hipEventDisableTiming));
+        B4D_HIP(hipEventRecord(p->mr_fork, st));
+        for (int l = 1; l < nl; ++l) {
+            if (!p->mr_aux[l]) {
+                const int rs = lane_stream(l - 1, &p->mr_aux[l]);
+                if (rs) return rs;
+            }
+            if (!p->mr_join[l]) B4D_HIP(hipEventCreateWithFlags(&p->mr_join[l], hipEventDisableTiming));
+            B4D_HIP(hipStreamWaitEvent(p->mr_aux[l], p->mr_fork, 0));
+        }
     }
     const size_t fp = (size_t)g.h * g.w;
-    for (int b0 = 0; b0 < batch; b0 += fpl) {
-        const int nf = std::min(fpl, batch - b0);
-        int rc;
-        float* pmax = p->mr_amax + p->mr_cap;
-        if ((rc = wmr_rows_fwd(frames + b0 * fp, p->mr_T, p->twx, pmax, g, nf, st))) return rc;
-        if ((rc = wmr_cols(p->mr_T, p->mr_filt, p->twy, pmax, p->mr_amax, g, nf, st, p->mr_sepx, p->mr_sepy, p->mr_balance))) return rc;
-        if ((rc = wmr_rows_inv(p->mr_T, out + b0 * fp, p->twx, p->mr_amax, g, nf, st))) return rc;
+    int rc = B4D_OK, grp = 0;
+    for (int b0 = 0; b0 < batch && rc == B4D_OK; b0 += fpl, ++grp) {
+        const int nf = std::min(fpl, batch - b0), lane = grp % nl;
+        hipStream_t ls = lane ? p->mr_aux[lane] : st;
+        float2* T = p->mr_T + (size_t)lane * p->mr_cap * g.Wh * g.Hp;
+        float* amax = p->mr_amax + (size_t)lane * p->mr_cap * (g.hp + 1);
+        float* pmax = amax + p->mr_cap;
+        rc = wmr_rows_fwd(frames + b0 * fp, T, p->twx, pmax, g, nf, ls);
+        if (rc == B4D_OK) rc = wmr_cols(T, p->mr_filt, p->twy, pmax, amax, g, nf, ls, p->mr_sepx, p->mr_sepy, p->mr_balance);
+        if (rc == B4D_OK) rc = wmr_rows_inv(T, out + b0 * fp, p->twx, amax, g, nf, ls);
     }
-    return B4D_OK;
+    for (int l = 1; l < nl; ++l) {
+        B4D_HIP(hipEventRecord(p->mr_join[l], p->mr_aux[l]));
+        B4D_HIP(hipStreamWaitEvent(st, p->mr_join[l], 0));
+    }
+    return rc;
 }
 
 // one frame through pad/normalise -> rows -> columns x filter -> inverse, on stream st with the work buffers of `lane`
@@ -1356,7 +1397,10 @@ static int wiener_lanes(b4d_wiener* p) {
             if (!L.padded) B4D_HIP(hipMalloc((void**)&L.padded, sizeof(float) * n));
             if (!L.amax) B4D_HIP(hipMalloc((void**)&L.amax, sizeof(float) * 256));
         }
-        if (!L.st) B4D_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        if (!L.st) {
+            const int rs = lane_stream(l, &L.st);
+            if (rs) return rs;
+        }
         if (!L.done) B4D_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     }
     B4D_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
