@@ -905,6 +905,7 @@ struct Lanes {
     // inter_bytes: intermediate bytes per frame; two lanes need 2 * sub <= chunk and groups of at least min_group_bytes of input
     // (below that the launches themselves are what a group costs: 256^2 frames in two lanes of 64, 2.3 against 2.9 M frames/s)
     int open(b4d_plan* p, hipStream_t s, int batch, size_t inter_bytes, size_t frame_bytes, bool allow_two, size_t min_group_bytes);
+    int fork(b4d_plan* p, hipStream_t s, bool want_two);   // the stream part alone (group sizes are the caller's)
     hipStream_t stream(int g) const { return two && (g & 1) ? pl->aux : st; }
     int slot(int g) const { return two ? (g & 1) : 0; }
     int close();   // joins the second lane into the caller's stream

@@ -72,15 +72,23 @@ int Lanes::open(b4d_plan* p, hipStream_t s, int batch, size_t inter_bytes, size_
         int groups = (batch + sub - 1) / sub;
         groups += groups & 1;
         sub = (batch + groups - 1) / groups;
-        if (!p->aux) {
-            const int rs = b4d::lane_stream(0, &p->aux);
-            if (rs) return rs;
-            B4D_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-            B4D_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-        }
-        B4D_HIP(hipEventRecord(p->ev_fork, st));
-        B4D_HIP(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
     }
+    return fork(p, s, two);
+}
+
+int Lanes::fork(b4d_plan* p, hipStream_t s, bool want_two) {
+    pl = p;
+    st = s;
+    two = want_two;
+    if (!two) return B4D_OK;
+    if (!p->aux) {
+        const int rs = b4d::lane_stream(0, &p->aux);
+        if (rs) return rs;
+    }
+    if (!p->ev_fork) B4D_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    if (!p->ev_join) B4D_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    B4D_HIP(hipEventRecord(p->ev_fork, st));
+    B4D_HIP(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
     return B4D_OK;
 }
 

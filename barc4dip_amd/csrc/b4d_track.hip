@@ -1091,7 +1091,11 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         return general_phase_correlation(pl, images, nimg, tpl_src, tpl_frame, tpl_roi, ntpl, pair_img, pair_tpl, npairs, subpixel, eps,
                                          out, peak_ij, st);
     const size_t fpix = (size_t)ny * nx, half = fpix / 2;
-    const int pc = std::max(1, std::min(npairs, pl->chunk * 4));  // pairs per launch group
+    // pairs per launch group; a call of more than one group runs on two lanes (Lanes, b4d_fft2d.hpp: alternate groups on the
+    // caller's stream and the library's second one, each with its own slot of the per-group buffers)
+    const int pc_one = std::max(1, std::min(npairs, pl->chunk * 4));
+    const bool two = npairs > pc_one / 2 && pc_one >= 64;   // cfg3 (1152 pairs, groups of 192): 226 -> 231 k pairs/s
+    const int pc = two ? (pc_one + 1) / 2 : pc_one, nslot = two ? 2 : 1;
     const int nsrc = nimg + ntpl;
     size_t need = 0;
     auto add = [&](size_t b) { need += ((b + 255) & ~(size_t)255) + 256; };
@@ -1101,13 +1105,13 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     add(sizeof(RowSrc) * nsrc);
     add(sizeof(double) * 2 * ROI_SPLIT * nsrc);
     add(sizeof(int) * 2 * (size_t)npairs);
-    add(sizeof(float2) * half * pc);          // G
-    add(sizeof(float) * (size_t)ny * pc);     // G of the Nyquist column
-    add(sizeof(float) * fpix * pc);           // magnitude maps
-    add(sizeof(float) * fpix * pc);           // median scratch (gathered bin)
-    add(sizeof(float) * 2048 * (size_t)pc);
-    add(sizeof(int) * 2048 * (size_t)pc);
-    add(sizeof(unsigned) * SEL_WORDS * (size_t)pc);   // select state of the median
+    add(sizeof(float2) * half * pc * nslot);          // G
+    add(sizeof(float) * (size_t)ny * pc * nslot);     // G of the Nyquist column
+    add(sizeof(float) * fpix * pc * nslot);           // magnitude maps
+    add(sizeof(float) * fpix * pc * nslot);           // median scratch (gathered bin)
+    add(sizeof(float) * 2048 * (size_t)pc * nslot);
+    add(sizeof(int) * 2048 * (size_t)pc * nslot);
+    add(sizeof(unsigned) * SEL_WORDS * (size_t)pc * nslot);   // select state of the median
     Arena ar;
     int rc = track_arena(pl, need, &ar);
     if (rc) return rc;
@@ -1117,13 +1121,13 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     RowSrc* srcs = ar.take<RowSrc>(nsrc);
     double* roi_part = ar.take<double>((size_t)2 * ROI_SPLIT * nsrc);
     int* pidx = ar.take<int>(2 * (size_t)npairs);
-    float2* g = ar.take<float2>(half * pc);
-    float* gnyq = ar.take<float>((size_t)ny * pc);
-    float* mag = ar.take<float>(fpix * pc);
-    float* medws = ar.take<float>(fpix * pc);
-    float* pval = ar.take<float>((size_t)2048 * pc);
-    int* pind = ar.take<int>((size_t)2048 * pc);
-    SelState* msel = reinterpret_cast<SelState*>(ar.take<unsigned>((size_t)SEL_WORDS * pc));
+    float2* g0 = ar.take<float2>(half * pc * nslot);
+    float* gnyq0 = ar.take<float>((size_t)ny * pc * nslot);
+    float* mag0 = ar.take<float>(fpix * pc * nslot);
+    float* medws0 = ar.take<float>(fpix * pc * nslot);
+    float* pval0 = ar.take<float>((size_t)2048 * pc * nslot);
+    int* pind0 = ar.take<int>((size_t)2048 * pc * nslot);
+    SelState* msel0 = reinterpret_cast<SelState*>(ar.take<unsigned>((size_t)SEL_WORDS * pc * nslot));
 
     // ---- source descriptors: images (full frame, z-scored), then templates (ROI, z-scored, zero elsewhere)
     std::vector<RowSrc> h(nsrc);
@@ -1155,10 +1159,21 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
             return rc;
     }
     // ---- pairs
-    for (int p0 = 0; p0 < npairs; p0 += pc) {
-        const int np = std::min(pc, npairs - p0);
+    Lanes ln;
+    if ((rc = ln.fork(pl, st, two))) return rc;
+    int grp = 0;
+    for (int p0 = 0; p0 < npairs; p0 += pc, ++grp) {
+        const int np = std::min(pc, npairs - p0), slot = ln.slot(grp);
+        hipStream_t ls = ln.stream(grp);
+        float2* g = g0 + half * pc * slot;
+        float* gnyq = gnyq0 + (size_t)ny * pc * slot;
+        float* mag = mag0 + fpix * pc * slot;
+        float* medws = medws0 + fpix * pc * slot;
+        float* pval = pval0 + (size_t)2048 * pc * slot;
+        int* pind = pind0 + (size_t)2048 * pc * slot;
+        SelState* msel = msel0 + (size_t)pc * slot;
         if ((rc = product_inverse<true>(pl, spec, nyq, pidx + p0, pidx + npairs + p0, spec, nyq, np, g, gnyq, (float)eps,
-                                        0u, st, srcs)))
+                                        0u, ls, srcs)))
             return rc;
         RowOutArgs ra{};
         ra.g = g;
@@ -1175,18 +1190,18 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         ra.sel_stride = SEL_WORDS;
         ra.pred_bin = pred;
         ra.compact = medws;
-        B4D_HIP(hipMemsetAsync(msel, 0, sizeof(SelState) * (size_t)pc, st));   // counts, cursors, verdicts
+        B4D_HIP(hipMemsetAsync(msel, 0, sizeof(SelState) * (size_t)pc, ls));   // counts, cursors, verdicts
         // With an expected median bin the common path never reads the map itself: partials, counts and the gathered bin come
         // out of the row pass, the 3 x 3 Taylor neighbourhood from three row pairs recomputed around the peak (C2R_ROWS).  The
         // 4 ny nx bytes per pair are written only for the pairs the expectation fails on (gated second pass below).
         const bool nomap = pred != 0u;
         ra.nomap = nomap ? 1 : 0;
         int nblk = 0;
-        if ((rc = dispatch_c2r(pl, ra, np, st, C2R_MAG, nullptr, &nblk))) return rc;
+        if ((rc = dispatch_c2r(pl, ra, np, ls, C2R_MAG, nullptr, &nblk))) return rc;
         if (nomap) {
             RowOutArgs rr = ra;
             rr.nblk = nblk;
-            if ((rc = dispatch_c2r(pl, rr, np, st, C2R_ROWS))) return rc;
+            if ((rc = dispatch_c2r(pl, rr, np, ls, C2R_ROWS))) return rc;
         }
         FinArgs fa{};
         fa.mag = mag;
@@ -1201,18 +1216,19 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
         fa.subpixel = subpixel;
         fa.eps = eps;
         fa.partial_map = nomap ? 1 : 0;
-        if ((rc = launch_track_fin2(fa, msel, pred, np, st))) return rc;
+        if ((rc = launch_track_fin2(fa, msel, pred, np, ls))) return rc;
         if (nomap) {   // full maps for the pairs left over (verdict word of the select state != 0: nothing to do)
             RowOutArgs rf = ra;
             rf.nomap = 0;
             rf.selw = nullptr;
             rf.gate = &msel[0].ok;
             rf.gate_stride = SEL_WORDS;
-            if ((rc = dispatch_c2r(pl, rf, np, st, C2R_MAG))) return rc;
+            if ((rc = dispatch_c2r(pl, rf, np, ls, C2R_MAG))) return rc;
         }
-        if ((rc = launch_track_fin_rest(fa, msel, np, st))) return rc;
+        if ((rc = launch_track_fin_rest(fa, msel, np, ls))) return rc;
         B4D_HIP(hipGetLastError());
     }
+    if ((rc = ln.close())) return rc;
     return B4D_OK;
 }
 
