@@ -126,7 +126,9 @@ def secondary_fft2d(torch, stack, cpu: bool):
     """SURVEY.md §8 row a1 (signal/fft.py:198-237): fftshift(fft2(frame)) of every frame of a resident stack -> complex64 full
     spectra, through the public fft2d_stack.  Model: 4 B in + 8 B out per pixel ("if fft2d's complex output is also
     materialised add 8 N^2").  Moved: the two passes of the implementation (b4d_spectrum.hip: real columns -> half spectrum along y,
-    4 + 4 B per pixel; rows of it -> every output row and its conjugate mirror, 4 + 8 B per pixel)."""
+    4 + 4 B per pixel; rows of it -> every output row and its conjugate mirror, 4 + 8 B per pixel).  The half spectrum between the
+    passes (8 of those 20 B) is written and read inside ~64-MiB launch groups on two streams, i.e. through the memory-side cache
+    (b4d_fft2d: Lanes); `moved` still counts it: it is what the kernels load and store."""
     from barc4dip_amd.signal.fft import fft2d_stack
 
     T, n = min(int(stack.shape[0]), 256), int(stack.shape[-1])
