@@ -26,6 +26,7 @@ std::recursive_mutex& scratch_mutex();
 
 // b4d_set_option switches (defined next to it, b4d_kernels.hip): routes only, never results; read once per entry-point call
 extern std::atomic<int> g_opt_track_predict;   // "track_predict_bin" 0 / 1 / 2
+extern std::atomic<int> g_opt_lanes;           // "lanes": two-lane launch groups (Lanes, b4d_fft2d.hpp); 0 = the caller's stream only
 extern std::atomic<int> g_opt_exp;             // "exp": development A/B switch (kernel variants under test; 0 = shipped)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for `kernel` on the CURRENT device, set once per (kernel address, device):

@@ -55,6 +55,7 @@ int lane_stream(int idx, hipStream_t* out) {
     return B4D_OK;
 }
 std::atomic<int> g_opt_track_predict{1};
+std::atomic<int> g_opt_lanes{1};
 std::atomic<int> g_opt_exp{0};
 // b4d_spectrum.hip
 int spectrum_rows_last(const b4d_plan* pl, float2* spec, const float* frames, int batch, float2* out, hipStream_t st);
@@ -65,7 +66,7 @@ int Lanes::open(b4d_plan* p, hipStream_t s, int batch, size_t inter_bytes, size_
     st = s;
     const int want = (int)std::max<size_t>(1, ((size_t)64 << 20) / std::max<size_t>(1, inter_bytes));
     // two lanes need two slots of the workspaces and enough work to pay for the fork / join (a few microseconds of host time)
-    two = allow_two && batch >= 2 && p->chunk >= 2 && (size_t)batch * frame_bytes >= 2 * min_group_bytes &&
+    two = allow_two && b4d::g_opt_lanes.load() != 0 && batch >= 2 && p->chunk >= 2 && (size_t)batch * frame_bytes >= 2 * min_group_bytes &&
           (size_t)std::min(want, p->chunk / 2) * frame_bytes >= min_group_bytes;
     sub = two ? std::min(want, p->chunk / 2) : p->chunk;   // one lane: the plan's own groups
     if (two) {   // an even number of groups of equal size
@@ -79,7 +80,7 @@ int Lanes::open(b4d_plan* p, hipStream_t s, int batch, size_t inter_bytes, size_
 int Lanes::fork(b4d_plan* p, hipStream_t s, bool want_two) {
     pl = p;
     st = s;
-    two = want_two;
+    two = want_two && b4d::g_opt_lanes.load() != 0;
     if (!two) return B4D_OK;
     if (!p->aux) {
         const int rs = b4d::lane_stream(0, &p->aux);
@@ -113,7 +114,7 @@ int b4d_set_option(const char* name, int value) {
         std::atomic<int>* v;
         int lo, hi;
     };
-    const Opt opts[] = {{"track_predict_bin", &g_opt_track_predict, 0, 2}, {"exp", &g_opt_exp, 0, 255}};
+    const Opt opts[] = {{"track_predict_bin", &g_opt_track_predict, 0, 2}, {"lanes", &g_opt_lanes, 0, 1}, {"exp", &g_opt_exp, 0, 255}};
     for (const Opt& o : opts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi)

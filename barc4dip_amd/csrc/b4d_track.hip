@@ -1094,7 +1094,7 @@ int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const flo
     // pairs per launch group; a call of more than one group runs on two lanes (Lanes, b4d_fft2d.hpp: alternate groups on the
     // caller's stream and the library's second one, each with its own slot of the per-group buffers)
     const int pc_one = std::max(1, std::min(npairs, pl->chunk * 4));
-    const bool two = npairs > pc_one / 2 && pc_one >= 64;   // cfg3 (1152 pairs, groups of 192): 226 -> 231 k pairs/s
+    const bool two = npairs > pc_one / 2 && pc_one >= 64 && g_opt_lanes.load() != 0;   // cfg3 (1152 pairs, groups of 192): 226 -> 231 k pairs/s
     const int pc = two ? (pc_one + 1) / 2 : pc_one, nslot = two ? 2 : 1;
     const int nsrc = nimg + ntpl;
     size_t need = 0;

@@ -1287,7 +1287,7 @@ static int wiener_mr_apply(b4d_wiener* p, const float* frames, int batch, float*
         const int n = e ? atoi(e) : 2;
         return n >= 1 && n <= b4d_wiener::MR_LANES ? n : 2;
     }();
-    const int nl = std::min(lanes_env, batch);
+    const int nl = g_opt_lanes.load() ? std::min(lanes_env, batch) : 1;
     int fpl = std::min(batch, wiener_fpl(nl > 1, sizeof(float2) * (size_t)g.Wh * g.Hp));
     if (nl > 1) fpl = std::min(fpl, (batch + nl - 1) / nl);
     if (fpl > p->mr_cap || nl > p->mr_slots) {   // work queued earlier on other streams may still use the old buffers: drain before freeing
@@ -1416,6 +1416,11 @@ int b4d_wiener_apply(b4d_wiener* p, const float* frames, int batch, float* out, 
     const size_t fp = (size_t)p->h * p->w;
     if (p->mr) return wiener_mr_apply(p, frames, batch, out, clip, st);
     if (batch == 1) return wiener_frame(p, 0, frames, out, clip, st);
+    if (!g_opt_lanes.load()) {   // option "lanes" 0: the caller's stream only
+        int r1 = B4D_OK;
+        for (int b = 0; b < batch && r1 == B4D_OK; ++b) r1 = wiener_frame(p, 0, frames + b * fp, out + b * fp, clip, st);
+        return r1;
+    }
     int rc = wiener_lanes(p);
     if (rc) return rc;
     // fork: the lanes start after everything already queued on the caller's stream; join: the caller's stream waits for all

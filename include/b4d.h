@@ -48,6 +48,11 @@ const char* b4d_last_error(void);
  *                        around the peak are recomputed for the sub-pixel step, pairs whose expectation fails get their full map
  *                        from a second, gated pass; 0 = no expectation: full maps, full select; 2 = a deliberately wrong
  *                        expectation (test hook: every pair takes the gated pass).
+ *   "lanes"              0 / 1 (default 1): 1 = the multi-pass entry points (b4d_fft2d, the general-size passes, b4d_wiener_apply,
+ *                        b4d_phase_correlation) cut a stack into cache-sized launch groups and deal them alternately to the
+ *                        caller's stream and ONE library-owned stream per device, forked from and joined into the caller's stream
+ *                        by events inside the call (stream order as seen by the caller is unchanged); 0 = everything on the
+ *                        caller's stream alone (for callers that must not see a second stream).
  *   "exp"                0 .. 255 (default 0): development switch for A/B runs of kernel variants under test in ONE process
  *                        (tools/dev_*.py); a shipped library has no reader of it.
  * Values outside an option's range and unknown names return B4D_EINVAL; the options are atomics, read once per entry-point call. */

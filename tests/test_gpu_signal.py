@@ -517,3 +517,45 @@ def test_fft2d_columns_first_rows_last(gs, shape):
     np.testing.assert_array_equal(G[inner], np.conj(M)[inner])
     for (y, x) in ((ny // 2, nx // 2), (0, nx // 2), (ny // 2, 0), (0, 0)):
         assert G[y, x].imag == 0.0
+
+
+def test_lanes_option_is_only_a_route(gs):
+    """b4d_set_option("lanes", 0 / 1) (include/b4d.h): the two-lane launch groups (cache-sized groups dealt to the caller's stream
+    and the library's second one) against everything on the caller's stream: bit-identical outputs for fft2d (power-of-two and
+    mixed-radix sizes), psd + autocorr at a detector format, the Wiener mixed-radix driver and phase-correlation pair groups, at
+    stack lengths that do not divide into the groups."""
+    import torch
+
+    from barc4dip_amd import _ffi
+    from barc4dip_amd.preprocessing import deconvolve_psf
+    from barc4dip_amd.signal.fft import fft2d_stack
+
+    lib = _ffi.lib()
+    rng = np.random.default_rng(5)
+    pow2 = torch.from_numpy((rng.poisson(300.0, size=(41, 1024, 1024))).astype(np.float32)).cuda()
+    det = torch.from_numpy((rng.poisson(300.0, size=(13, 1080, 1920))).astype(np.float32)).cuda()
+    small = torch.from_numpy((rng.poisson(300.0, size=(7, 512, 512))).astype(np.float32)).cuda()
+    stack, _ = synth.shifted_stack(4, 256, seed=3, max_shift=6)
+    rois = [(y, y + 61, x, x + 61) for y in (20, 90, 160) for x in (25, 95, 165)]
+    tpl_frame = [0] * 9 + [max(t - 1, 0) for t in range(4) for _ in range(9)]
+    tpl_roi = rois + rois * 4
+    pair_img = [t for t in range(4) for _ in range(9)] * 2
+    pair_tpl = [k for _ in range(4) for k in range(9)] + [9 + 9 * t + k for t in range(4) for k in range(9)]
+    out = {}
+    try:
+        for lanes in (1, 0):
+            assert lib.b4d_set_option(b"lanes", lanes) == 0
+            psd, ac = gs.psd_autocorr2d_stack(det, return_tensors=True)[:2]
+            out[lanes] = (fft2d_stack(pow2, return_tensors=True).cpu().numpy(), fft2d_stack(det, return_tensors=True).cpu().numpy(),
+                          psd.cpu().numpy(), ac.cpu().numpy(), deconvolve_psf(small, sigma=1.5, return_tensors=True).cpu().numpy(),
+                          gs.phase_correlation_batch(stack, stack, tpl_frame, tpl_roi, pair_img, pair_tpl))
+            torch.cuda.synchronize()
+    finally:
+        lib.b4d_set_option(b"lanes", 1)
+    assert lib.b4d_set_option(b"lanes", 2) != 0
+    for a, b in zip(out[1], out[0]):
+        np.testing.assert_array_equal(a, b)
+    from oracle import signal_np as S
+
+    assert nerr(out[1][0][40], S.fft2d(pow2[40].cpu().numpy().astype(np.float64))[0]) < TOL
+    assert nerr(out[1][1][12], S.fft2d(det[12].cpu().numpy().astype(np.float64))[0]) < TOL
