@@ -573,6 +573,7 @@ extern "C" int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int 
     const size_t oV = take(blk), oW = take(blk), oX = take(blk);
     const size_t part_elems = std::max<size_t>((size_t)nblk * 3, (size_t)nsplit * NB * NB) * batch;
     const size_t oP = take(sizeof(double) * part_elems), oP2 = take(sizeof(double) * part_elems);
+    const size_t oPc = take(sizeof(double) * part_elems), oPc2 = take(sizeof(double) * part_elems);   // partials of the convergence check
     const size_t oR = take(sizeof(float) * NB * NB * batch), oE = take(sizeof(double) * 8 * batch), oS = take(sizeof(double) * 3 * batch);
     void* ws = nullptr;
     int rc = get_scratch(bytes, &ws, (hipStream_t)stream);
@@ -585,6 +586,8 @@ extern "C" int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int 
     float* X = reinterpret_cast<float*>(base + oX);
     double* part = reinterpret_cast<double*>(base + oP);
     double* part2 = reinterpret_cast<double*>(base + oP2);
+    double* partc = reinterpret_cast<double*>(base + oPc);
+    double* partc2 = reinterpret_cast<double*>(base + oPc2);
     float* Rinv = reinterpret_cast<float*>(base + oR);
     double* evd = reinterpret_cast<double*>(base + oE);
     double* stat = reinterpret_cast<double*>(base + oS);
@@ -616,35 +619,93 @@ extern "C" int b4d_sta2_eigenvalues(const float* frames, int batch, int ny, int 
     B4D_HIP(hipGetLastError());
     std::vector<double> prev((size_t)batch * 8, 0.0), cur((size_t)batch * 8), hstat((size_t)3 * batch);
     const int max_cycles = 120, check_every = 2;   // 3 multiplications by G per cycle
-    bool done = false;
+    // The convergence check (two float64 Gram matrices, the 32 x 32 Ritz problem -- one workgroup per item, ~220 us of latency --
+    // and a copy to the host) runs on the library's second stream while the caller's stream goes on with the next two cycles; the
+    // host reads a check when the next one is due.  The values checked, the cycles at which they are taken and the result are
+    // those of the serial loop; the last two cycles queued before the verdict arrives are the price (they touch scratch only).
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_part = nullptr;
+    if (!g_opt_lanes.load() || lane_stream(1, &aux) != B4D_OK || hipEventCreateWithFlags(&ev_part, hipEventDisableTiming) != hipSuccess)
+        aux = nullptr;   // option "lanes" 0 (or no second stream): the serial loop
+    struct EvGuard {
+        hipEvent_t& a;
+        ~EvGuard() {
+            if (a) (void)hipEventDestroy(a);
+        }
+    } ev_guard{ev_part};
+    bool done = false, pending = false, first_check = true;
     int ncyc = 0;
+    auto verdict = [&]() {   // cur holds a finished check
+        bool ok = true;
+        for (int b = 0; b < batch; ++b) {
+            const double ref = std::max(std::fabs(cur[(size_t)b * 8]), 1e-300);
+            for (int k = 0; k < 8; ++k)
+                if (!(std::fabs(cur[(size_t)b * 8 + k] - prev[(size_t)b * 8 + k]) <= 2e-7 * ref)) ok = false;
+        }
+        prev = cur;
+        return ok;
+    };
+    auto collect = [&]() -> int {   // wait for the check in flight on the second stream
+        B4D_HIP(hipMemcpyAsync(cur.data(), evd, sizeof(double) * cur.size(), hipMemcpyDeviceToHost, aux));
+        if (first_check) B4D_HIP(hipMemcpyAsync(hstat.data(), stat, sizeof(double) * hstat.size(), hipMemcpyDeviceToHost, aux));
+        B4D_HIP(hipStreamSynchronize(aux));
+        first_check = false;
+        pending = false;
+        return B4D_OK;
+    };
     for (int cyc = 0; cyc < max_cycles && !done; ++cyc) {
         ncyc = cyc + 1;
         symm(V, W);
         if ((cyc + 1) % check_every == 0 || cyc == max_cycles - 1) {
-            hipLaunchKernelGGL(k_gram64, dim3(nsplit, batch), dim3(1024), 0, st, V, W, m, part);
-            hipLaunchKernelGGL(k_gram64, dim3(nsplit, batch), dim3(1024), 0, st, V, V, m, part2);
-            hipLaunchKernelGGL(k_ritz, dim3(batch), dim3(1024), 0, st, part, part2, nsplit, evd);
-            B4D_HIP(hipGetLastError());
-            B4D_HIP(hipMemcpyAsync(cur.data(), evd, sizeof(double) * cur.size(), hipMemcpyDeviceToHost, st));
-            B4D_HIP(hipStreamSynchronize(st));
-            done = true;
-            for (int b = 0; b < batch; ++b) {
-                const double ref = std::max(std::fabs(cur[(size_t)b * 8]), 1e-300);
-                for (int k = 0; k < 8; ++k)
-                    if (!(std::fabs(cur[(size_t)b * 8 + k] - prev[(size_t)b * 8 + k]) <= 2e-7 * ref)) done = false;
+            if (aux) {
+                if (pending) {
+                    if ((rc = collect())) return rc;
+                    if (verdict()) {
+                        done = true;
+                        ncyc = cyc + 1 - check_every;
+                        break;
+                    }
+                }
+                // the Gram partials of a check have buffers of their own: the next cycle's orthonormalisation reuses `part`
+                hipLaunchKernelGGL(k_gram64, dim3(nsplit, batch), dim3(1024), 0, st, V, W, m, partc);
+                hipLaunchKernelGGL(k_gram64, dim3(nsplit, batch), dim3(1024), 0, st, V, V, m, partc2);
+                B4D_HIP(hipGetLastError());
+                B4D_HIP(hipEventRecord(ev_part, st));
+                B4D_HIP(hipStreamWaitEvent(aux, ev_part, 0));
+                hipLaunchKernelGGL(k_ritz, dim3(batch), dim3(1024), 0, aux, partc, partc2, nsplit, evd);
+                B4D_HIP(hipGetLastError());
+                pending = true;
+                if (cyc == max_cycles - 1) {
+                    if ((rc = collect())) return rc;
+                    done = verdict();
+                    break;
+                }
+                // (the next check collects this one on the host before its partials overwrite partc / partc2)
+            } else {
+                hipLaunchKernelGGL(k_gram64, dim3(nsplit, batch), dim3(1024), 0, st, V, W, m, part);
+                hipLaunchKernelGGL(k_gram64, dim3(nsplit, batch), dim3(1024), 0, st, V, V, m, part2);
+                hipLaunchKernelGGL(k_ritz, dim3(batch), dim3(1024), 0, st, part, part2, nsplit, evd);
+                B4D_HIP(hipGetLastError());
+                B4D_HIP(hipMemcpyAsync(cur.data(), evd, sizeof(double) * cur.size(), hipMemcpyDeviceToHost, st));
+                B4D_HIP(hipStreamSynchronize(st));
+                done = verdict();
+                if (done) break;
             }
-            prev = cur;
-            if (done) break;
         }
         symm(W, X);
         symm(X, W);
         orthonormalise();
         B4D_HIP(hipGetLastError());
     }
+    if (pending) {   // (not reached: the last cycle collects its own check)
+        if ((rc = collect())) return rc;
+        done = verdict();
+    }
     if (getenv("B4D_DEBUG_EIG")) fprintf(stderr, "[b4d_sta2] batch %d m %d cycles %d converged %d\n", batch, m, ncyc, (int)done);
-    B4D_HIP(hipMemcpyAsync(hstat.data(), stat, sizeof(double) * hstat.size(), hipMemcpyDeviceToHost, st));
-    B4D_HIP(hipStreamSynchronize(st));
+    if (!aux) {
+        B4D_HIP(hipMemcpyAsync(hstat.data(), stat, sizeof(double) * hstat.size(), hipMemcpyDeviceToHost, st));
+        B4D_HIP(hipStreamSynchronize(st));
+    }
     const double denom = (double)npix - 1.0;
     for (int b = 0; b < batch; ++b)
         for (int k = 0; k < nout; ++k) {

@@ -21,7 +21,7 @@ from . import kernels as K
 from .common import (choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
                      tile_spans, tiled_scalar_fields, tiles_meta)
 from .speckles import (_dev2d, _fft_ok, _pad4, _pad_square_batch, _pad_square_dev, _tile_batches, _widths_batch, _widths_from_autocorr,
-                       tiled_fields_batched, tiled_fields_batched_multi)
+                       tile_batch_memo, tiled_fields_batched, tiled_fields_batched_multi)
 from .statistics import distribution_moments, moments_from_sums
 
 logger = logging.getLogger(__name__)
@@ -247,6 +247,7 @@ def _tiles_pointwise(t, tile_mode, groups, saturation_value, eps):
     return _tiles_pointwise_multi(t[None], tile_mode, groups, saturation_value, eps)[0]
 
 
+@tile_batch_memo.scoped
 def sharpness_stats_batch(tb, *, groups: set, tiles: bool = True, saturation_value: float | None = 65535.0,
                           eps: float = 1e-6) -> list[dict]:
     """{"full": ..., "tiles": ...} of every frame of a (B, H, W) device stack (already in display orientation): the
@@ -312,6 +313,7 @@ def sharpness_stats_batch(tb, *, groups: set, tiles: bool = True, saturation_val
     return outs
 
 
+@tile_batch_memo.scoped
 def sharpness_stats(image: np.ndarray, *, metrics: str | Sequence[str] = "all", tiles: bool = True,
                     display_origin: Literal["upper", "lower"] = "lower", saturation_value: float | None = 65535.0,
                     eps: float = 1e-6, verbose: bool = True) -> dict:
