@@ -37,8 +37,63 @@ def to_device_f32(a, *, ndim: tuple[int, ...]):
         raise ValueError(f"expected ndim in {ndim}, got {arr.ndim}")
     # NumPy's FFT promotes everything except float16 / float32 to double precision: outputs follow that dtype
     src_dtype = np.float32 if arr.dtype in (np.float32, np.float16) else np.float64
+    if arr.nbytes >= _UPLOAD_MIN_BYTES and arr.flags.c_contiguous and arr.dtype.name in _UPLOAD_CODES and arr.dtype != np.float32:
+        return _upload_staged(arr), False, src_dtype
     t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to("cuda", non_blocking=False)
     return t, False, src_dtype
+
+
+# ---- large host arrays that are not float32 (the host -> HBM half): a host-side astype of detector words runs
+# at 1-4 GB/s on one core.  Integer and float64 arrays of 32 MiB and more go up in their NATIVE dtype (uint16 detector words stay
+# 2 bytes on the bus) through two page-locked 32-MiB blocks filled by a few host threads (NumPy releases the GIL while copying)
+# while the previous block is on the bus, and are converted to float32 on the device (b4d_to_f32: the same round-to-nearest
+# conversion as ndarray.astype).  8 x 2048^2 frames (tools/dev_upload.py): uint16 16.2 -> 2.4 ms, float64 21.4 -> 7.4 ms; float32
+# arrays keep the plain copy (2.7 ms against 3.3 staged: the runtime's own staging is as fast).  Everything stays on the caller's
+# stream.
+_UPLOAD_MIN_BYTES = 32 << 20
+_UPLOAD_BLOCK = 32 << 20
+_UPLOAD_CODES = {"uint8": 0, "uint16": 1, "int16": 2, "int32": 3, "uint32": 4, "float32": 5, "float64": 6}
+_upload_pool = None
+
+
+def _upload_staged(arr: np.ndarray):
+    global _upload_pool
+    torch = _ffi.require_gpu()
+    from concurrent.futures import ThreadPoolExecutor
+
+    if _upload_pool is None:
+        _upload_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="b4d-upload")
+    lib = _ffi.lib()
+    code, item = _UPLOAD_CODES[arr.dtype.name], arr.dtype.itemsize
+    flat = arr.reshape(-1)
+    n = int(flat.size)
+    out = torch.empty(arr.shape, dtype=torch.float32, device="cuda")
+    oflat = out.view(-1)
+    per = _UPLOAD_BLOCK // item
+    pinned = [torch.empty(per * item, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    raw = None if code == 5 else [torch.empty(per * item, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    sent = [None, None]
+    stream = torch.cuda.current_stream()
+    for k, a in enumerate(range(0, n, per)):
+        b, slot = min(n, a + per), k & 1
+        if sent[slot] is not None:
+            sent[slot].synchronize()        # the block's previous copy has left the page-locked buffer
+        host = pinned[slot].numpy()[:(b - a) * item].view(arr.dtype)
+        q = max(1, -(-(b - a) // 4))
+        list(_upload_pool.map(lambda lo: np.copyto(host[lo:lo + q], flat[a + lo:min(b, a + lo + q)]), range(0, b - a, q)))
+        if code == 5:
+            oflat[a:b].copy_(pinned[slot][:(b - a) * item].view(torch.float32), non_blocking=True)
+        else:
+            raw[slot][:(b - a) * item].copy_(pinned[slot][:(b - a) * item], non_blocking=True)
+            _ffi.check(lib.b4d_to_f32(C.c_void_p(raw[slot].data_ptr()), code, b - a, C.c_void_p(oflat[a:b].data_ptr()),
+                                      C.c_void_p(stream.cuda_stream)))
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        sent[slot] = ev
+    for ev in sent:
+        if ev is not None:
+            ev.synchronize()                # the page-locked blocks go back to torch's host allocator only once they are idle
+    return out
 
 
 def ptr(t) -> C.c_void_p:

@@ -118,3 +118,37 @@ def test_to_f32_every_dtype_aligned_and_not(prep):
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy(), host[off:].astype(np.float32)), (dt, n, off)
     assert lib.b4d_to_f32(C.c_void_p(raw.data_ptr()), 9, 4, C.c_void_p(out.data_ptr()), None) != 0
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "uint16", "int16", "int32", "uint32", "float32", "float64"])
+def test_large_host_arrays_go_up_in_their_native_dtype(prep, dtype):
+    """_device.to_device_f32 (every entry point's way in): host arrays of 32 MiB and more are staged through page-locked blocks in
+    their native dtype and converted on the device -- bit-identical to ndarray.astype(float32), for sizes that do not divide into
+    the blocks, values at the ends of the integer ranges, NaN / Inf, and the small-array route next to it."""
+    import torch
+
+    from barc4dip_amd import _device as D
+
+    rng = np.random.default_rng(11)
+    dt = np.dtype(dtype)
+    n_items = (40 << 20) // dt.itemsize + 12345          # > one block, not a multiple of anything
+    if dt.kind in "ui":
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, info.max, size=n_items, dtype=dt, endpoint=True)
+        a[:4] = (info.max, info.min, info.max - 1, 0)
+    else:
+        a = (rng.standard_normal(n_items) * 1e4).astype(dt)
+        a[:6] = (np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-40)
+    shape = (3, 1, n_items // 3) if n_items % 3 == 0 else (1, 1, n_items)
+    a = a.reshape(shape)
+    assert a.nbytes >= D._UPLOAD_MIN_BYTES
+    t, was_tensor, src = D.to_device_f32(a, ndim=(3,))
+    assert not was_tensor and t.dtype == torch.float32 and tuple(t.shape) == shape
+    assert src == (np.float32 if dtype == "float32" else np.float64)
+    np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32), a.astype(np.float32).view(np.uint32))
+    small = a.reshape(-1)[:100003].reshape(1, 1, -1)
+    np.testing.assert_array_equal(D.to_device_f32(small, ndim=(3,))[0].cpu().numpy().view(np.uint32),
+                                  small.astype(np.float32).view(np.uint32))
+    # a non-contiguous view of a large array takes the ordinary route
+    v = a[:, :, ::2]
+    np.testing.assert_array_equal(D.to_device_f32(v, ndim=(3,))[0].cpu().numpy().view(np.uint32), v.astype(np.float32).view(np.uint32))
