@@ -101,7 +101,7 @@ def ptr(t) -> C.c_void_p:
 
 
 _PINNED_MIN_BYTES = 1 << 20      # below this a plain .cpu() is as fast
-_PINNED_MAX_BYTES = 256 << 20    # above this the result is not worth page-locking: pageable copy
+_PINNED_MAX_BYTES = 1 << 30      # above this the result is not page-locked as a whole: staged through two blocks (_download_staged)
 
 
 def to_host(t, dtype=None) -> np.ndarray:
@@ -114,6 +114,8 @@ def to_host(t, dtype=None) -> np.ndarray:
     t = t.detach()
     want = t.dtype if dtype is None else torch.from_numpy(np.empty(0, dtype=dtype)).dtype
     nbytes = t.numel() * torch.empty(0, dtype=want).element_size()
+    if t.is_cuda and nbytes > _PINNED_MAX_BYTES and t.is_contiguous():
+        return _download_staged(t, want)
     if not t.is_cuda or nbytes < _PINNED_MIN_BYTES or nbytes > _PINNED_MAX_BYTES:
         out = t.cpu().numpy()
         return out.astype(dtype, copy=False) if dtype is not None else out
@@ -121,6 +123,45 @@ def to_host(t, dtype=None) -> np.ndarray:
     host.copy_(t if want == t.dtype else t.to(want), non_blocking=True)
     torch.cuda.current_stream().synchronize()
     return host.numpy()
+
+
+def _download_staged(t, want):
+    """Results beyond 256 MB (the (T, N, N) float64 autocorrelation stack of speckle_stack_stats ...): converted on the device block
+    by block, copied into two page-locked 32-MiB blocks and from there into the (pageable) result by a few host threads while the
+    next block is on the bus -- instead of one pageable copy + a single-threaded astype of the whole array."""
+    global _upload_pool
+    torch = _ffi.require_gpu()
+    from concurrent.futures import ThreadPoolExecutor
+
+    if _upload_pool is None:
+        _upload_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="b4d-upload")
+    item = torch.empty(0, dtype=want).element_size()
+    out = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=want).numpy().dtype)
+    oflat, tflat = out.reshape(-1), t.reshape(-1)
+    n, per = int(tflat.numel()), _UPLOAD_BLOCK // item
+    pinned = [torch.empty(per, dtype=want, pin_memory=True) for _ in range(2)]
+    ready = [None, None]
+    spans = [(a, min(n, a + per)) for a in range(0, n, per)]
+    stream = torch.cuda.current_stream()
+
+    def drain(k):
+        a, b = spans[k]
+        ready[k & 1].synchronize()
+        host = pinned[k & 1].numpy()[:b - a]
+        q = max(1, -(-(b - a) // 4))
+        list(_upload_pool.map(lambda lo: np.copyto(oflat[a + lo:min(b, a + lo + q)], host[lo:lo + q]), range(0, b - a, q)))
+
+    for k, (a, b) in enumerate(spans):
+        if k >= 2:
+            drain(k - 2)                    # the block this one will overwrite has been copied out
+        src = tflat[a:b]
+        pinned[k & 1][:b - a].copy_(src if want == t.dtype else src.to(want), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        ready[k & 1] = ev
+    for k in range(max(0, len(spans) - 2), len(spans)):
+        drain(k)
+    return out
 
 
 def result_dtype(a):

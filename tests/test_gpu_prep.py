@@ -152,3 +152,25 @@ def test_large_host_arrays_go_up_in_their_native_dtype(prep, dtype):
     # a non-contiguous view of a large array takes the ordinary route
     v = a[:, :, ::2]
     np.testing.assert_array_equal(D.to_device_f32(v, ndim=(3,))[0].cpu().numpy().view(np.uint32), v.astype(np.float32).view(np.uint32))
+
+
+def test_large_results_come_down_through_page_locked_blocks(prep):
+    """_device.to_host beyond its whole-result page-locking limit (_download_staged): device-side conversion block by block, host
+    threads copying out of two page-locked blocks -- equal to .cpu().numpy().astype(...), block count odd / even, ragged tail."""
+    import torch
+
+    from barc4dip_amd import _device as D
+
+    t = torch.randn(3, 7, 1234567, device="cuda") * 1e3          # 25.9 M elements: 4 blocks as float32, 7 as float64
+    t[0, 0, :3] = torch.tensor([float("nan"), float("inf"), -0.0], device="cuda")
+    ref = t.cpu().numpy()
+    for want in (torch.float64, torch.float32):
+        got = D._download_staged(t, want)
+        assert got.shape == tuple(t.shape) and got.dtype == (np.float64 if want == torch.float64 else np.float32)
+        np.testing.assert_array_equal(got, ref.astype(got.dtype))
+    old = D._PINNED_MAX_BYTES
+    try:
+        D._PINNED_MAX_BYTES = 16 << 20                           # route the public entry through it
+        np.testing.assert_array_equal(D.to_host(t, np.float64), ref.astype(np.float64))
+    finally:
+        D._PINNED_MAX_BYTES = old
