@@ -374,9 +374,17 @@ __global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, SelState* __rest
     __shared__ int si[16];
     const size_t pair = blockIdx.x;
     if (!sel[pair].ok) return;    // the expectation failed: k_track_fin does the whole selection on the map
-    const int mny = p.ny, mnx = p.nx, oy = p.ny / 2, ox = p.nx / 2;
+    int mny = p.ny, mnx = p.nx, oy = p.ny / 2, ox = p.nx / 2;
+    if (p.geom) {   // template matching: compact (rows, columns) maps, shifts counted from the template's position
+        mny = p.geom[4 * pair];
+        mnx = p.geom[4 * pair + 1];
+        oy = p.geom[4 * pair + 2];
+        ox = p.geom[4 * pair + 3];
+    }
     const unsigned n = (unsigned)mny * mnx;
-    const float* mag = p.mag + pair * (size_t)n;
+    const size_t stride = p.stride ? p.stride : (size_t)n;
+    const float* mag = p.mag + pair * stride;
+    const float* msrc = p.med_src ? p.med_src + pair * stride : mag;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < p.nblk; i += blockDim.x)
@@ -398,7 +406,7 @@ __global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, SelState* __rest
     __syncthreads();
     // ---- median (np.median of a float32 map): passes 2-3 of the select on the gathered bin
     const SelState ss = sel[pair];
-    const float* cx = p.compact + pair * (size_t)n;
+    const float* cx = p.compact + pair * stride;
     const unsigned cn = ss.count;
     unsigned nl, ne;
     float med;
@@ -414,7 +422,7 @@ __global__ void __launch_bounds__(1024) k_track_fin2(FinArgs p, SelState* __rest
                     if (threadIdx.x == 0) sel[pair].ok = 0u;
                     return;
                 }
-                kb = next_larger_key(mag, n, ka, hist);
+                kb = next_larger_key(msrc, n, ka, hist);
             }
             b = key2f(kb);
         }
@@ -431,6 +439,16 @@ static int launch_track_fin2(const FinArgs& fa, SelState* sel, unsigned pred, in
     }
     const size_t n = (size_t)fa.ny * fa.nx;
     hipLaunchKernelGGL(k_track_select, dim3((pairs + 63) / 64), dim3(64), 0, st, n, sel, pred, pairs);
+    hipLaunchKernelGGL(k_track_fin2, dim3(pairs), dim3(1024), FIN_LDS, st, fa, sel);
+    B4D_HIP(hipGetLastError());
+    return B4D_OK;
+}
+// template matching: the verdicts come from k_ncc_check
+static int launch_track_fin2_checked(const FinArgs& fa, SelState* sel, int pairs, hipStream_t st) {
+    {
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_track_fin2), FIN_LDS);
+        if (rc_lds) return rc_lds;
+    }
     hipLaunchKernelGGL(k_track_fin2, dim3(pairs), dim3(1024), FIN_LDS, st, fa, sel);
     B4D_HIP(hipGetLastError());
     return B4D_OK;
@@ -589,47 +607,173 @@ struct NccArgs {
     int* geom;            // (pairs, 4) map rows, columns, origin (y0, x0) for the epilogue
     int ny, nx, nblk;
     int img_h, img_w;     // extent of the images inside the (ny, nx) canvas (zero beyond)
+    // the median of |map| (peak quality): pred[pair] = top-11-bit key bin expected to hold it (k_ncc_sample; 0 = none); the map
+    // kernel counts the elements below / inside that bin into sel[pair] and gathers the bin into gathered + pair * stride
+    const unsigned* pred;
+    SelState* sel;
+    float* gathered;
 };
 
+// one value of the zero-mean normalised cross-correlation map (element (i, j) of the valid region)
+struct NccPair {
+    const double *s1, *s2;
+    const float* xc;
+    double tmean, tssd, vol;
+    int h, y0, x0;
+    size_t W1;
+};
+__device__ __forceinline__ NccPair ncc_pair(const NccArgs& p, int pair, const RowSrc& ts) {
+    NccPair q;
+    const size_t W1 = (size_t)p.nx + 1;
+    const size_t slot = (size_t)p.tpl_widx[p.pair_tpl[pair]] * p.nimg + p.pair_img[pair];
+    q.s1 = p.sat1 + slot * (p.ny + 1) * W1;
+    q.s2 = p.sat2 + slot * (p.ny + 1) * W1;
+    q.xc = p.xc + (size_t)pair * p.ny * p.nx;
+    q.tmean = p.tstat[2 * p.pair_tpl[pair]];
+    q.tssd = p.tstat[2 * p.pair_tpl[pair] + 1];
+    q.h = ts.y1 - ts.y0;
+    q.vol = (double)q.h * (ts.x1 - ts.x0);
+    q.y0 = ts.y0;
+    q.x0 = ts.x0;
+    q.W1 = W1;
+    return q;
+}
+__device__ __forceinline__ float ncc_value(const NccPair& q, int ny, int nx, int i, int j) {
+    const size_t a = (size_t)i * q.W1 + j, b = (size_t)(i + q.h) * q.W1 + j;
+    const double S1 = q.s1[b] - q.s1[a];
+    const double S2 = q.s2[b] - q.s2[a];
+    const int yy = (ny / 2 + i - q.y0) & (ny - 1), xx = (nx / 2 + j - q.x0) & (nx - 1);
+    const double num = (double)q.xc[(size_t)yy * nx + xx] - S1 * q.tmean;
+    const double den = sqrt(fmax((S2 - S1 * S1 / q.vol) * q.tssd, 0.0));
+    // (measured: a float32 reciprocal square root instead of the float64 square root and division is worth 1.5 % -- the kernel
+    // waits for its four window-sum loads, not for the arithmetic -- and moves the last bit of the map: not taken)
+    return den > 1.1920928955078125e-07 ? (float)(num / den) : 0.f;
+}
+
+// The bin of the median of |map|, guessed from NCC_SAMPLES evenly spaced elements.  grid (pairs), block 256.  Exactness never
+// depends on the guess: k_ncc_map counts what lies below / inside the bin, k_ncc_check accepts the pair only if the middle rank
+// falls inside it, every other pair takes the whole select on its map (k_track_fin).
+constexpr int NCC_SAMPLES = 4096;
+__global__ void __launch_bounds__(256) k_ncc_sample(NccArgs p, unsigned* __restrict__ pred) {
+    __shared__ unsigned hist[1024];
+    __shared__ unsigned sh_total;
+    const int pair = blockIdx.x;
+    const RowSrc ts = p.tsrc[p.pair_tpl[pair]];
+    const NccPair q = ncc_pair(p, pair, ts);
+    const int hv = p.img_h - q.h + 1, wv = p.img_w - (ts.x1 - ts.x0) + 1;
+    const unsigned n = (unsigned)hv * (unsigned)wv, step = max(1u, n / NCC_SAMPLES);
+    for (int b = threadIdx.x; b < 1024; b += 256) hist[b] = 0u;
+    if (threadIdx.x == 0) sh_total = 0u;
+    __syncthreads();
+    unsigned mine = 0;
+    for (unsigned sidx = threadIdx.x; sidx < NCC_SAMPLES; sidx += 256) {
+        const unsigned e = sidx * step;
+        if (e >= n) break;
+        const float a = fabsf(ncc_value(q, p.ny, p.nx, (int)(e / wv), (int)(e % wv)));
+        if (a == a) {
+            atomicAdd(&hist[__float_as_uint(a) >> 21], 1u);
+            ++mine;
+        }
+    }
+    atomicAdd(&sh_total, mine);
+    __syncthreads();
+    if (threadIdx.x < 64) {   // lane l scans bins 16 l .. 16 l + 15
+        const unsigned total = sh_total, k = total / 2;
+        unsigned sum = 0;
+        for (int b = 0; b < 16; ++b) sum += hist[16 * threadIdx.x + b];
+        unsigned incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += t;
+        }
+        if (total == 0u && threadIdx.x == 0) pred[pair] = 0u;
+        unsigned below = incl - sum;
+        if (total != 0u && k >= below && k < incl)
+            for (int b = 0; b < 16; ++b) {
+                const unsigned c = hist[16 * threadIdx.x + b];
+                if (k < below + c) {
+                    pred[pair] = 1024u + 16u * threadIdx.x + (unsigned)b;   // f2key of a non-negative float: bits | 0x80000000
+                    break;
+                }
+                below += c;
+            }
+    }
+}
+
+// grid (ceil(pairs / 64)), block 64: the guess holds for pair i when the middle rank falls inside its bin and the whole bin was gathered
+__global__ void __launch_bounds__(64) k_ncc_check(const int* __restrict__ geom, const unsigned* __restrict__ pred, SelState* __restrict__ sel,
+                                                  int pairs) {
+    const int pair = blockIdx.x * 64 + threadIdx.x;
+    if (pair >= pairs) return;
+    SelState* st = sel + pair;
+    const unsigned n = (unsigned)geom[4 * pair] * (unsigned)geom[4 * pair + 1];
+    const unsigned k = (n & 1u) ? n / 2 : n / 2 - 1;
+    st->bin = pred[pair];
+    st->ok = (pred[pair] != 0u && k >= st->below && k < st->below + st->count && st->fill == st->count) ? 1u : 0u;
+}
+
+
 // zero-mean normalised cross-correlation at every "valid" window position (signal/tracking.py:157-167: the arithmetic
-// of cv2.TM_CCOEFF_NORMED / skimage.match_template).  grid (nblk, pairs), block 256
+// of cv2.TM_CCOEFF_NORMED / skimage.match_template).  grid (nblk, pairs), block 256; a workgroup owns at most NCC_STAGE consecutive
+// elements: it writes the map and |map|, keeps a first-occurrence arg-max partial, counts the |map| keys below / inside the
+// expected median bin and gathers the bin (staged in LDS: ONE returning atomic per workgroup).
+constexpr int NCC_STAGE = 4096;
 __global__ void __launch_bounds__(256) k_ncc_map(NccArgs p) {
     __shared__ float sv[4];
     __shared__ int si[4];
+    __shared__ float stage[NCC_STAGE];
+    __shared__ unsigned cursor, nbelow, gbase;
     const int pair = blockIdx.y;
     const RowSrc ts = p.tsrc[p.pair_tpl[pair]];
-    const int h = ts.y1 - ts.y0, w = ts.x1 - ts.x0, hv = p.img_h - h + 1, wv = p.img_w - w + 1, n = hv * wv;
-    const double tmean = p.tstat[2 * p.pair_tpl[pair]], tssd = p.tstat[2 * p.pair_tpl[pair] + 1], vol = (double)h * w;
-    const size_t W1 = (size_t)p.nx + 1, fpix = (size_t)p.ny * p.nx;
-    const size_t slot = (size_t)p.tpl_widx[p.pair_tpl[pair]] * p.nimg + p.pair_img[pair];
-    const double* s1 = p.sat1 + slot * (p.ny + 1) * W1;
-    const double* s2 = p.sat2 + slot * (p.ny + 1) * W1;
-    const float* xc = p.xc + pair * fpix;
+    const NccPair q = ncc_pair(p, pair, ts);
+    const int hv = p.img_h - q.h + 1, wv = p.img_w - (ts.x1 - ts.x0) + 1, n = hv * wv;
+    const size_t fpix = (size_t)p.ny * p.nx;
+    const unsigned want = p.pred ? p.pred[pair] : 0u;
+    if (threadIdx.x == 0) cursor = nbelow = 0u;
+    __syncthreads();
     const int per = (n + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * per, e1 = min(n, e0 + per);
+    const int lane = threadIdx.x & 63;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
-        const int i = e / wv, j = e % wv;
-        const size_t a = (size_t)i * W1 + j, b = (size_t)(i + h) * W1 + j;
-        const double S1 = s1[b] - s1[a];
-        const double S2 = s2[b] - s2[a];
-        const int yy = (p.ny / 2 + i - ts.y0) & (p.ny - 1), xx = (p.nx / 2 + j - ts.x0) & (p.nx - 1);
-        const double num = (double)xc[(size_t)yy * p.nx + xx] - S1 * tmean;
-        const double den = sqrt(fmax((S2 - S1 * S1 / vol) * tssd, 0.0));
-        const float r = den > 1.1920928955078125e-07 ? (float)(num / den) : 0.f;
-        p.ncc[pair * fpix + e] = r;
-        p.absncc[pair * fpix + e] = fabsf(r);
-        argmax_merge(bv, bi, r, e);
+    unsigned below = 0;
+    for (int eb = e0; eb < e1; eb += 256) {   // whole wavefronts stay in the loop (ballot)
+        const int e = eb + threadIdx.x;
+        bool hit = false;
+        float a = 0.f;
+        if (e < e1) {
+            const float r = ncc_value(q, p.ny, p.nx, e / wv, e % wv);
+            a = fabsf(r);
+            p.ncc[pair * fpix + e] = r;
+            p.absncc[pair * fpix + e] = a;
+            argmax_merge(bv, bi, r, e);
+            if (want && a == a) {   // NaNs are not ranked (b4d_select.hpp)
+                const unsigned key = 1024u + (__float_as_uint(a) >> 21);
+                below += key < want ? 1u : 0u;
+                hit = key == want;
+            }
+        }
+        if (want) {
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&cursor, (unsigned)__popcll(m));
+                base = __shfl(base, 0, 64);
+                if (hit) stage[base + __popcll(m & ((1ull << lane) - 1ull))] = a;   // per <= NCC_STAGE: never past the end
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_down(bv, o, 64);
         const int oi = __shfl_down(bi, o, 64);
         argmax_merge(bv, bi, ov, oi);
+        below += __shfl_down(below, o, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         sv[threadIdx.x >> 6] = bv;
         si[threadIdx.x >> 6] = bi;
+        if (below) atomicAdd(&nbelow, below);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -642,6 +786,19 @@ __global__ void __launch_bounds__(256) k_ncc_map(NccArgs p) {
             p.geom[4 * pair + 2] = ts.y0;
             p.geom[4 * pair + 3] = ts.x0;
         }
+        if (want) {
+            if (nbelow) atomicAdd(&p.sel[pair].below, nbelow);
+            if (cursor) {
+                atomicAdd(&p.sel[pair].count, cursor);
+                gbase = atomicAdd(&p.sel[pair].fill, cursor);
+            }
+        }
+    }
+    __syncthreads();
+    if (want) {
+        const unsigned cnt = cursor, base = gbase;
+        float* out = p.gathered + pair * fpix + base;
+        for (unsigned t = threadIdx.x; t < cnt; t += 256) out[t] = stage[t];
     }
 }
 
@@ -1257,7 +1414,8 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     hipStream_t st = (hipStream_t)stream;
     const size_t fpix = (size_t)ny * nx, half = fpix / 2, satn = (size_t)(ny + 1) * (nx + 1);
     const int pc = std::max(1, std::min(npairs, pl->chunk * 2));
-    const int nsrc = nimg + ntpl, nblk = 256;
+    // workgroups per map: at most NCC_STAGE elements each (the gathered median bin is staged in LDS)
+    const int nsrc = nimg + ntpl, nblk = std::max(256, (int)(((size_t)img_h * img_w + NCC_STAGE - 1) / NCC_STAGE));
     size_t need = 0;
     auto add = [&](size_t b) { need += ((b + 255) & ~(size_t)255) + 256; };
     add(sizeof(float2) * half * nsrc);
@@ -1281,10 +1439,12 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     add(sizeof(double) * 2 * (size_t)ntpl);
     add(sizeof(float2) * half * pc);
     add(sizeof(float) * (size_t)ny * pc);
-    for (int i = 0; i < 3; ++i) add(sizeof(float) * fpix * pc);
+    for (int i = 0; i < 4; ++i) add(sizeof(float) * fpix * pc);
     add(sizeof(float) * (size_t)nblk * pc);
     add(sizeof(int) * (size_t)nblk * pc);
     add(sizeof(int) * 4 * (size_t)pc);
+    add(sizeof(unsigned) * (size_t)pc);
+    add(sizeof(unsigned) * SEL_WORDS * (size_t)pc);
     Arena ar;
     int rc = track_arena(pl, need, &ar);
     if (rc) return rc;
@@ -1307,6 +1467,9 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     float* pval = ar.take<float>((size_t)nblk * pc);
     int* pind = ar.take<int>((size_t)nblk * pc);
     int* geom = ar.take<int>(4 * (size_t)pc);
+    float* gathered = ar.take<float>(fpix * pc);
+    unsigned* pred = ar.take<unsigned>((size_t)pc);
+    SelState* msel = reinterpret_cast<SelState*>(ar.take<unsigned>((size_t)SEL_WORDS * pc));
 
     std::vector<RowSrc> h(nsrc);
     for (int i = 0; i < nimg; ++i) h[i] = RowSrc{i, 0, img_h, 0, img_w, 0.f, 1.f, 0};
@@ -1378,7 +1541,14 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
             na.nblk = nblk;
             na.img_h = img_h;
             na.img_w = img_w;
+            const bool expect = g_opt_track_predict.load() != 0;   // "track_predict_bin" 0: the whole select on every map
+            na.pred = expect ? pred : nullptr;
+            na.sel = msel;
+            na.gathered = gathered;
+            B4D_HIP(hipMemsetAsync(msel, 0, sizeof(SelState) * (size_t)np, st));
+            if (expect) hipLaunchKernelGGL(k_ncc_sample, dim3(np), dim3(256), 0, st, na, pred);
             hipLaunchKernelGGL(k_ncc_map, dim3(nblk, np), dim3(256), 0, st, na);
+            if (expect) hipLaunchKernelGGL(k_ncc_check, dim3((np + 63) / 64), dim3(64), 0, st, geom, pred, msel, np);
             FinArgs fa{};
             fa.mag = ncc;
             fa.med_src = absncc;
@@ -1394,7 +1564,12 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
             fa.nblk = nblk;
             fa.subpixel = subpixel;
             fa.eps = eps;
-            if ((rc = launch_track_fin(fa, np, st))) return rc;
+            if (expect) {   // passes 2-3 of the select on the gathered bin; whoever is left takes the whole select on its map
+                FinArgs fg = fa;
+                fg.compact = gathered;
+                if ((rc = launch_track_fin2_checked(fg, msel, np, st))) return rc;
+            }
+            if ((rc = launch_track_fin_rest(fa, msel, np, st))) return rc;
             B4D_HIP(hipGetLastError());
         }
     }

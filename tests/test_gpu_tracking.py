@@ -473,3 +473,34 @@ def test_phase_correlation_skimage_backend_vs_oracle(gs, shape):
     g64 = gs.phase_correlation(tpl.astype(np.float64), fr.astype(np.float64), slices_yx=sl, backend="skimage")
     w64 = P.phase_correlation_skimage(tpl.astype(np.float64), fr.astype(np.float64), slices_yx=sl)
     assert g64[:2] == w64[:2]
+
+
+@pytest.mark.parametrize("backend", ["opencv", "skimage"])
+def test_template_matching_median_guess_is_only_a_route(gs, backend):
+    """b4d_template_match guesses the bin of the median of |NCC map| from 4096 samples, counts and gathers that bin while the map
+    is written and finishes the select on the gathered values; pairs whose middle rank falls elsewhere (and every pair with
+    "track_predict_bin" 0) take the whole select on their map.  Both routes: bit-identical rows and arg-max indices -- on speckle
+    frames, on a frame with a constant region (maps full of exact zeros: the guess fails there) and on a non-power-of-two frame."""
+    from barc4dip_amd import _ffi
+
+    stack, sh = synth.shifted_stack(4, 512, seed=21, max_shift=10)
+    flat = stack.copy()
+    flat[:, 200:, :] = 5.0                                  # constant lower part: zero-variance windows -> r = 0 exactly
+    odd = stack[:, :300, :417].copy()
+    rois = [(100, 161, 90, 171), (30, 121, 280, 341)]
+    tpl_frame = [0, 0] + [max(t - 1, 0) for t in range(4) for _ in range(2)]
+    tpl_roi = rois + rois * 4
+    pair_img = [t for t in range(4) for _ in range(2)] * 2
+    pair_tpl = [k for _ in range(4) for k in range(2)] + [2 + 2 * t + k for t in range(4) for k in range(2)]
+    lib = _ffi.lib()
+    out = {}
+    try:
+        for mode in (1, 0):
+            assert lib.b4d_set_option(b"track_predict_bin", mode) == 0
+            out[mode] = [gs.template_matching_batch(x, x, tpl_frame, tpl_roi, pair_img, pair_tpl, backend=backend, return_peak_ij=True)
+                         for x in (stack, flat, odd)]
+    finally:
+        lib.b4d_set_option(b"track_predict_bin", 1)
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
+    assert np.all(np.rint(out[1][0][0][:8, 0]).reshape(4, 2) == sh[:, 0:1])
