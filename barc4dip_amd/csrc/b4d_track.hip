@@ -1202,26 +1202,39 @@ int b4d_xcorr2d(b4d_plan* pl, const float* a, const float* b, int batch, float* 
     float* ra_rows = ar.take<float>(ny * chunk);
     float* rb_rows = ar.take<float>(ny * chunk);
     float* gnyq = ar.take<float>(ny * chunk);
-    float* part = ar.take<float>((size_t)256 * chunk);
-    for (int b0 = 0; b0 < batch; b0 += chunk) {
-        const int nb = std::min(chunk, batch - b0);
-        if ((rc = forward_spectra(pl, a + b0 * fpix, nullptr, nb, sa, ra_rows, fa, st))) return rc;
-        if ((rc = forward_spectra(pl, b + b0 * fpix, nullptr, nb, sb, rb_rows, fb, st))) return rc;
-        if ((rc = product_inverse<false>(pl, sa, fa, nullptr, nullptr, sb, fb, nb, g, gnyq, 0.f, flags, st))) return rc;
+    float* part0 = ar.take<float>((size_t)256 * chunk);
+    // two-lane launch groups (Lanes, b4d_fft2d.hpp): 2048^2 16.3 -> 17.1 k pairs/s, 1024^2 50.5 -> 54.7 k (tools/dev_xcorr_chunk.py);
+    // lane l works in slot l (sub items) of every chunk buffer
+    // (groups of half the plan's chunk: the column kernels of this route want thousands of tiles per launch, 4-frame groups lose)
+    Lanes ln;
+    const bool two = chunk >= 2 && batch >= 2 && (size_t)batch * fpix * sizeof(float) >= ((size_t)32 << 20);
+    if ((rc = ln.fork(pl, st, two))) return rc;
+    ln.sub = ln.two ? std::max(1, std::min(chunk / 2, (batch + 1) / 2)) : chunk;
+    int grp = 0;
+    for (int b0 = 0; b0 < batch && rc == B4D_OK; b0 += ln.sub, ++grp) {
+        const int nb = std::min(ln.sub, batch - b0);
+        const size_t so = (size_t)ln.slot(grp) * ln.sub;
+        hipStream_t ls = ln.stream(grp);
+        float2 *sa_ = sa + half * so, *sb_ = sb + half * so, *g_ = g + half * so, *fa_ = fa + ny * so, *fb_ = fb + ny * so;
+        float *ra_ = ra_rows + ny * so, *rb_ = rb_rows + ny * so, *gn_ = gnyq + ny * so, *part = part0 + 256 * so;
+        if ((rc = forward_spectra(pl, a + b0 * fpix, nullptr, nb, sa_, ra_, fa_, ls))) break;
+        if ((rc = forward_spectra(pl, b + b0 * fpix, nullptr, nb, sb_, rb_, fb_, ls))) break;
+        if ((rc = product_inverse<false>(pl, sa_, fa_, nullptr, nullptr, sb_, fb_, nb, g_, gn_, 0.f, flags, ls))) break;
         RowOutArgs ra{};
-        ra.g = g;
-        ra.gnyq = gnyq;
+        ra.g = g_;
+        ra.gnyq = gn_;
         ra.out = corr + b0 * fpix;
         ra.tw = pl->tw_x;
         ra.scale = 1.0f / ((float)pl->nx * (float)pl->ny);
         ra.ny = pl->ny;
         ra.ct_w = pl->ct_w;
         ra.flags = 0;
-        if ((rc = dispatch_c2r(pl, ra, nb, st, C2R_OUT))) return rc;
+        if ((rc = dispatch_c2r(pl, ra, nb, ls, C2R_OUT))) break;
         if (flags & B4D_NORM_PEAK)
-            if ((rc = normalise_by_absmax(corr + b0 * fpix, fpix, nb, part, st))) return rc;
+            if ((rc = normalise_by_absmax(corr + b0 * fpix, fpix, nb, part, ls))) break;
     }
-    return B4D_OK;
+    const int rj = ln.close();
+    return rc ? rc : rj;
 }
 
 int b4d_phase_correlation(b4d_plan* pl, const float* images, int nimg, const float* tpl_src, int ntplsrc,

@@ -555,6 +555,26 @@ def test_lanes_option_is_only_a_route(gs):
     assert lib.b4d_set_option(b"lanes", 2) != 0
     for a, b in zip(out[1], out[0]):
         np.testing.assert_array_equal(a, b)
+    # b4d_xcorr2d over a stack of pairs (the Python signature takes one pair): power-of-two and mixed-radix plans
+    import ctypes as C
+
+    for frames in (pow2[:24], det[:12]):
+        T, ny, nx = (int(v) for v in frames.shape)
+        plan = _ffi.get_plan(ny, nx, general=not (ny & (ny - 1) == 0 and nx & (nx - 1) == 0))
+        other = torch.roll(frames, shifts=(3, -5), dims=(1, 2)).contiguous()
+        res = {}
+        try:
+            for lanes in (1, 0):
+                assert lib.b4d_set_option(b"lanes", lanes) == 0
+                corr = torch.empty_like(frames)
+                _ffi.check(lib.b4d_xcorr2d(plan.handle, C.c_void_p(frames.data_ptr()), C.c_void_p(other.data_ptr()), T,
+                                           C.c_void_p(corr.data_ptr()), _ffi.REMOVE_MEAN | _ffi.NORM_PEAK, _ffi.stream_ptr()))
+                res[lanes] = corr.cpu().numpy()
+        finally:
+            lib.b4d_set_option(b"lanes", 1)
+        np.testing.assert_array_equal(res[1], res[0])
+        peak = np.unravel_index(int(np.argmax(res[1][T - 1])), (ny, nx))
+        assert peak == (ny // 2 - 3, nx // 2 + 5), peak
     from oracle import signal_np as S
 
     assert nerr(out[1][0][40], S.fft2d(pow2[40].cpu().numpy().astype(np.float64))[0]) < TOL
