@@ -19,7 +19,7 @@ from ..signal import corr as _corr
 from ..signal import fft as _fft
 from . import kernels as K
 from .common import (choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
-                     tile_spans, tiled_scalar_fields, tiles_meta)
+                     tile_spans, tiles_meta)
 from .speckles import (_dev2d, _fft_ok, _pad4, _pad_square_batch, _pad_square_dev, _tile_batches, _widths_batch, _widths_from_autocorr,
                        tile_batch_memo, tiled_fields_batched, tiled_fields_batched_multi)
 from .statistics import distribution_moments, moments_from_sums
@@ -252,8 +252,6 @@ def sharpness_stats_batch(tb, *, groups: set, tiles: bool = True, saturation_val
                           eps: float = 1e-6) -> list[dict]:
     """{"full": ..., "tiles": ...} of every frame of a (B, H, W) device stack (already in display orientation): the
     arithmetic of sharpness_stats, kernels launched once per batch / tile shape (used by sharpness_stack_stats)."""
-    import torch
-
     b, h, w = (int(v) for v in tb.shape)
     if h * w == 0:
         raise ValueError("sharpness_stats received an empty image.")

@@ -26,7 +26,6 @@ from ..maths.stats import (distance_at_fraction_from_peak, distances_at_fraction
                            widths_at_fraction_batch)
 from ..signal import corr as _corr
 from ..signal import fft as _fft
-from ..signal.tracking import phase_correlation_batch, template_matching_batch
 from . import kernels as K
 from .common import (choose_tiling_mode, grids_to_fields, normalize_groups, stack_time_series,
                      tile_spans, tiles_meta)
