@@ -351,35 +351,31 @@ __global__ void __launch_bounds__(1024) k_ritz(const double* __restrict__ partT,
     A0[p][q] = t;
     A1[p][q] = sv;
     __syncthreads();
-    if (threadIdx.x < 64) {  // Cholesky of S (A1) into L; lane i owns row i
-        const int i = threadIdx.x;
+    // Cholesky of S (A1) into L and the two triangular solves, right-looking on the whole workgroup: once column j (row i) is final,
+    // every element of the trailing part takes its one update.  Each element sees the same products subtracted in the same
+    // (ascending) order as in the row-by-row form -- bit-identical results -- in 32 short steps per phase instead of a
+    // 500-step dependent chain on one wavefront (the check sits on the critical path of small batches: tile grids).
+    {
         double tr = 0.0;
         for (int c = 0; c < NB; ++c) tr += A1[c][c];
         const double floor_piv = tr * 1e-14 + 1e-300;
         for (int j = 0; j < NB; ++j) {
-            double v = 0.0;
-            if (i < NB && i >= j) {
-                v = A1[i][j];
-                for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
-            }
-            double piv = __shfl(v, j, 64);
+            double piv = A1[j][j];
             if (!(piv > floor_piv)) piv = floor_piv;
             const double d = sqrt(piv);
-            if (i < NB && i >= j) L[i][j] = (i == j) ? d : v / d;
-            __threadfence_block();
+            if (q == j && p >= j) L[p][j] = p > j ? A1[p][j] / d : d;
+            __syncthreads();
+            if (p > j && q > j && q <= p) A1[p][q] -= L[p][j] * L[q][j];
+            __syncthreads();
         }
     }
-    __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {
-        if (threadIdx.x < NB) {  // forward substitution L X = A0, column c in place
-            const int c = threadIdx.x;
-            for (int i = 0; i < NB; ++i) {
-                double v = A0[i][c];
-                for (int k = 0; k < i; ++k) v -= L[i][k] * A0[k][c];
-                A0[i][c] = v / L[i][i];
-            }
+        for (int i = 0; i < NB; ++i) {  // forward substitution L X = A0 in place: row i final, then its share of every later row
+            if (p == i) A0[i][q] = A0[i][q] / L[i][i];
+            __syncthreads();
+            if (p > i) A0[p][q] -= L[p][i] * A0[i][q];
+            __syncthreads();
         }
-        __syncthreads();
         const double x = A0[q][p];
         __syncthreads();
         A0[p][q] = x;  // transpose: second pass applies L^-1 from the other side
