@@ -555,6 +555,20 @@ def test_lanes_option_is_only_a_route(gs):
     assert lib.b4d_set_option(b"lanes", 2) != 0
     for a, b in zip(out[1], out[0]):
         np.testing.assert_array_equal(a, b)
+    # the power-of-two psd + autocorr pipeline takes two lanes from 4096^2 frames on
+    big = torch.from_numpy(rng.poisson(300.0, size=(5, 4096, 4096)).astype(np.float32)).cuda()
+    res = {}
+    try:
+        for lanes in (1, 0):
+            assert lib.b4d_set_option(b"lanes", lanes) == 0
+            psd, ac = gs.psd_autocorr2d_stack(big, return_tensors=True)[:2]
+            res[lanes] = (psd.cpu().numpy(), ac.cpu().numpy())
+    finally:
+        lib.b4d_set_option(b"lanes", 1)
+    np.testing.assert_array_equal(res[1][0], res[0][0])
+    np.testing.assert_array_equal(res[1][1], res[0][1])
+    assert res[1][1][4, 2048, 2048] == 1.0
+    del big, res
     # b4d_xcorr2d over a stack of pairs (the Python signature takes one pair): power-of-two and mixed-radix plans
     import ctypes as C
 
