@@ -545,7 +545,27 @@ __global__ void __launch_bounds__(64) k_sat_cols(int ny, int nx, double* __restr
     if (x > nx) return;
     const size_t W1 = (size_t)nx + 1, base = (size_t)blockIdx.y * (ny + 1) * W1;
     double r1 = 0.0, r2 = 0.0;
-    for (int y = 1; y <= ny; ++y) {
+    // one column per lane, 1025 wavefronts for 64 images: the running sums are a dependent chain, the loads are not -- eight rows
+    // of both tables are requested before the first is added (same order of additions, same bits)
+    int y = 1;
+    for (; y + 7 <= ny; y += 8) {
+        double a1[8], a2[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const size_t o = base + (size_t)(y + t) * W1 + x;
+            a1[t] = sat1[o];
+            a2[t] = sat2[o];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const size_t o = base + (size_t)(y + t) * W1 + x;
+            r1 += a1[t];
+            r2 += a2[t];
+            sat1[o] = r1;
+            sat2[o] = r2;
+        }
+    }
+    for (; y <= ny; ++y) {
         const size_t o = base + (size_t)y * W1 + x;
         r1 += sat1[o];
         r2 += sat2[o];
