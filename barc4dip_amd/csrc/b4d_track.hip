@@ -465,8 +465,9 @@ static int launch_track_fin_rest(const FinArgs& fa, SelState* sel, int pairs, hi
 // Summed-area tables (float64) of the image as the matcher sees it, v = (x - mean) / denom in float32 (raw image:
 // mean 0, denom 1), and of v^2: sat[(y + 1) (nx + 1) + x + 1] = sum over rows <= y, columns <= x.
 // Row pass: grid (ny, nimg), block 256; column pass: grid (ceil((nx + 1) / 64), nimg), block 64.
-// win > 0: the row holds the WINDOW sums H(y, j) = sum_{x = j .. j + win - 1} instead of the prefix (then the column pass
-// yields V(y, j) = sum_{y' < y} H(y', j) and a window sum is V(i + h, j) - V(i, j): two loads instead of four).
+// win > 0: the row holds the WINDOW sums H(y, j) = sum_{x = j .. j + win - 1} instead of the prefix; the column pass then sums the h
+// rows under each window position (k_sat_cols), so that the matcher reads ONE value per table and position instead of four
+// corners (k_ncc_map waits for exactly these loads: 1.09 -> 0.97 ms per group of 192 pairs).
 __global__ void __launch_bounds__(256) k_sat_rows(const float* __restrict__ frames, int ny, int nx, const RowSrc* __restrict__ srcs,
                                                   double* __restrict__ sat1, double* __restrict__ sat2, int win) {
     __shared__ double s1[256], s2[256];
@@ -540,37 +541,45 @@ __global__ void __launch_bounds__(256) k_sat_rows(const float* __restrict__ fram
     }
 }
 
-__global__ void __launch_bounds__(64) k_sat_cols(int ny, int nx, double* __restrict__ sat1, double* __restrict__ sat2) {
+// Column pass: the sum of the h rows of window sums under each window position, D(i, j) = sum_{y = i .. i + h - 1} H(y, j), as a
+// running window down the column (row i of the table receives D(i, .); rows beyond ny - h are not used).  One column per lane;
+// the running sum is a dependent chain, the loads are not: eight rows of both tables are requested before the first is added.
+__global__ void __launch_bounds__(64) k_sat_cols(int ny, int nx, double* __restrict__ sat1, double* __restrict__ sat2, int h) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     if (x > nx) return;
-    const size_t W1 = (size_t)nx + 1, base = (size_t)blockIdx.y * (ny + 1) * W1;
-    double r1 = 0.0, r2 = 0.0;
-    // one column per lane, 1025 wavefronts for 64 images: the running sums are a dependent chain, the loads are not -- eight rows
-    // of both tables are requested before the first is added (same order of additions, same bits)
-    int y = 1;
-    for (; y + 7 <= ny; y += 8) {
-        double a1[8], a2[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const size_t o = base + (size_t)(y + t) * W1 + x;
-            a1[t] = sat1[o];
-            a2[t] = sat2[o];
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const size_t o = base + (size_t)(y + t) * W1 + x;
-            r1 += a1[t];
-            r2 += a2[t];
-            sat1[o] = r1;
-            sat2[o] = r2;
-        }
+    const size_t W1 = (size_t)nx + 1, base = (size_t)blockIdx.y * (ny + 1) * W1 + x;
+    double w1 = 0.0, w2 = 0.0;
+    for (int y = 1; y <= h; ++y) {   // H(y - 1) sits in row y
+        w1 += sat1[base + (size_t)y * W1];
+        w2 += sat2[base + (size_t)y * W1];
     }
-    for (; y <= ny; ++y) {
-        const size_t o = base + (size_t)y * W1 + x;
-        r1 += sat1[o];
-        r2 += sat2[o];
-        sat1[o] = r1;
-        sat2[o] = r2;
+    const int last = ny - h;         // D(0 .. last)
+    int i = 0;
+    if (h >= 8)
+        for (; i + 8 <= last; i += 8) {
+            double in1[8], in2[8], out1[8], out2[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {   // entering row H(i + t + h), leaving row H(i + t)
+                in1[t] = sat1[base + (size_t)(i + t + h + 1) * W1];
+                in2[t] = sat2[base + (size_t)(i + t + h + 1) * W1];
+                out1[t] = sat1[base + (size_t)(i + t + 1) * W1];
+                out2[t] = sat2[base + (size_t)(i + t + 1) * W1];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                sat1[base + (size_t)(i + t) * W1] = w1;
+                sat2[base + (size_t)(i + t) * W1] = w2;
+                w1 = (w1 + in1[t]) - out1[t];
+                w2 = (w2 + in2[t]) - out2[t];
+            }
+        }
+    for (; i <= last; ++i) {
+        sat1[base + (size_t)i * W1] = w1;
+        sat2[base + (size_t)i * W1] = w2;
+        if (i < last) {
+            w1 = (w1 + sat1[base + (size_t)(i + h + 1) * W1]) - sat1[base + (size_t)(i + 1) * W1];
+            w2 = (w2 + sat2[base + (size_t)(i + h + 1) * W1]) - sat2[base + (size_t)(i + 1) * W1];
+        }
     }
 }
 
@@ -612,9 +621,9 @@ __global__ void __launch_bounds__(1024) k_tpl_stats(const float* __restrict__ fr
 
 struct NccArgs {
     const float* xc;      // (pairs, ny, nx) shifted circular cross-correlation sum I[p + d] T[p], d = index - (ny/2, nx/2)
-    const double* sat1;   // (nwidths, nimg, ny + 1, nx + 1) column-prefixed window sums (k_sat_rows with win = template width)
+    const double* sat1;   // (nshapes, nimg, ny + 1, nx + 1) window sums per template shape (k_sat_rows over the width, k_sat_cols over the height)
     const double* sat2;
-    const int* tpl_widx;  // template -> width slot
+    const int* tpl_widx;  // template -> shape slot
     int nimg;
     const int* pair_img;
     const int* pair_tpl;
@@ -659,9 +668,9 @@ __device__ __forceinline__ NccPair ncc_pair(const NccArgs& p, int pair, const Ro
     return q;
 }
 __device__ __forceinline__ float ncc_value(const NccPair& q, int ny, int nx, int i, int j) {
-    const size_t a = (size_t)i * q.W1 + j, b = (size_t)(i + q.h) * q.W1 + j;
-    const double S1 = q.s1[b] - q.s1[a];
-    const double S2 = q.s2[b] - q.s2[a];
+    const size_t a = (size_t)i * q.W1 + j;
+    const double S1 = q.s1[a];   // window sums of the image and of its square under the template at (i, j): one load each
+    const double S2 = q.s2[a];
     const int yy = (ny / 2 + i - q.y0) & (ny - 1), xx = (nx / 2 + j - q.x0) & (nx - 1);
     const double num = (double)q.xc[(size_t)yy * nx + xx] - S1 * q.tmean;
     const double den = sqrt(fmax((S2 - S1 * S1 / q.vol) * q.tssd, 0.0));
@@ -1457,12 +1466,15 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     add(sizeof(RowSrc) * nsrc);
     add(sizeof(double) * 2 * ROI_SPLIT * nsrc);
     add(sizeof(int) * 3 * (size_t)npairs);
-    std::vector<int> widths, widx(ntpl);   // distinct template widths: one pair of window-sum tables per (width, image)
+    std::vector<int> widths, heights, widx(ntpl);   // distinct template shapes: one pair of window-sum tables per (shape, image)
     for (int k = 0; k < ntpl; ++k) {
-        const int w = tpl_roi[4 * k + 3] - tpl_roi[4 * k + 2];
+        const int w = tpl_roi[4 * k + 3] - tpl_roi[4 * k + 2], hh = tpl_roi[4 * k + 1] - tpl_roi[4 * k];
         size_t j = 0;
-        while (j < widths.size() && widths[j] != w) ++j;
-        if (j == widths.size()) widths.push_back(w);
+        while (j < widths.size() && (widths[j] != w || heights[j] != hh)) ++j;
+        if (j == widths.size()) {
+            widths.push_back(w);
+            heights.push_back(hh);
+        }
         widx[k] = (int)j;
     }
     const size_t nw = widths.size();
@@ -1525,7 +1537,8 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     for (size_t j = 0; j < nw; ++j) {
         hipLaunchKernelGGL(k_sat_rows, dim3(ny, nimg), dim3(256), 0, st, images, ny, nx, srcs, sat1 + j * satn * nimg, sat2 + j * satn * nimg,
                            widths[j]);
-        hipLaunchKernelGGL(k_sat_cols, dim3((nx + 64) / 64, nimg), dim3(64), 0, st, ny, nx, sat1 + j * satn * nimg, sat2 + j * satn * nimg);
+        hipLaunchKernelGGL(k_sat_cols, dim3((nx + 64) / 64, nimg), dim3(64), 0, st, ny, nx, sat1 + j * satn * nimg, sat2 + j * satn * nimg,
+                           heights[j]);
     }
     B4D_HIP(hipGetLastError());
     const int fc = std::max(1, pl->chunk * 2);
