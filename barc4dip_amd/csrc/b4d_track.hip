@@ -496,6 +496,31 @@ __global__ void __launch_bounds__(256) k_sat_rows(const float* __restrict__ fram
     double r1 = s1[threadIdx.x] - a1, r2 = s2[threadIdx.x] - a2;  // exclusive prefix of this thread's segment
     double* o1 = sat1 + base + (size_t)(y + 1) * W1;
     double* o2 = sat2 + base + (size_t)(y + 1) * W1;
+    if (y == 0)
+        for (int x = threadIdx.x; x <= nx; x += 256) {
+            sat1[base + x] = 0.0;
+            sat2[base + x] = 0.0;
+        }
+    if (win > 0) {   // the row's prefix P (P[x] = sum of the first x values) stays in LDS; the table receives P[j + win] - P[j]
+        extern __shared__ double pre[];   // 2 (nx + 1) doubles
+        double* p1 = pre;
+        double* p2 = pre + (nx + 1);
+        for (int x = x0; x < x1; ++x) {
+            const double v = (double)((row[x] - sd.mean) * inv);
+            r1 += v;
+            r2 = fma(v, v, r2);
+            p1[x + 1] = r1;
+            p2[x + 1] = r2;
+        }
+        if (threadIdx.x == 0) p1[0] = p2[0] = 0.0;
+        __syncthreads();
+        for (int j = threadIdx.x; j <= nx; j += 256) {   // lanes along the row: whole lines per store
+            const bool full = j + win <= nx;
+            o1[j] = full ? p1[j + win] - p1[j] : 0.0;
+            o2[j] = full ? p2[j + win] - p2[j] : 0.0;
+        }
+        return;
+    }
     for (int x = x0; x < x1; ++x) {
         const double v = (double)((row[x] - sd.mean) * inv);
         r1 += v;
@@ -506,38 +531,6 @@ __global__ void __launch_bounds__(256) k_sat_rows(const float* __restrict__ fram
     if (threadIdx.x == 0) {
         o1[0] = 0.0;
         o2[0] = 0.0;
-    }
-    if (y == 0)
-        for (int x = threadIdx.x; x <= nx; x += 256) {
-            sat1[base + x] = 0.0;
-            sat2[base + x] = 0.0;
-        }
-    if (win > 0) {   // prefix P (o[x] = sum of the first x values) -> window sums, in place: read both ends, barrier, write
-        __threadfence_block();
-        __syncthreads();
-        double pa1[16], pb1[16], pa2[16], pb2[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int j = x0 + k;
-            const bool in = k < per && j < x1, full = in && j + win <= nx;
-            pa1[k] = in ? o1[j] : 0.0;
-            pa2[k] = in ? o2[j] : 0.0;
-            pb1[k] = full ? o1[j + win] : pa1[k];
-            pb2[k] = full ? o2[j + win] : pa2[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int j = x0 + k;
-            if (k < per && j < x1) {
-                o1[j] = pb1[k] - pa1[k];
-                o2[j] = pb2[k] - pa2[k];
-            }
-        }
-        if (threadIdx.x == 0) {
-            o1[nx] = 0.0;
-            o2[nx] = 0.0;
-        }
     }
 }
 
@@ -1535,8 +1528,10 @@ int b4d_template_match(b4d_plan* pl, const float* images, int nimg, const float*
     if ((rc = roi_stats(tpl_src, ny, nx, eps, srcs + nimg, ntpl, roi_part + (size_t)2 * ROI_SPLIT * nimg, st))) return rc;
     hipLaunchKernelGGL(k_tpl_stats, dim3(ntpl), dim3(1024), 0, st, tpl_src, ny, nx, srcs + nimg, tstat);
     for (size_t j = 0; j < nw; ++j) {
-        hipLaunchKernelGGL(k_sat_rows, dim3(ny, nimg), dim3(256), 0, st, images, ny, nx, srcs, sat1 + j * satn * nimg, sat2 + j * satn * nimg,
-                           widths[j]);
+        const size_t row_lds = sizeof(double) * 2 * ((size_t)nx + 1);
+        if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_sat_rows), row_lds))) return rc;
+        hipLaunchKernelGGL(k_sat_rows, dim3(ny, nimg), dim3(256), row_lds, st, images, ny, nx, srcs, sat1 + j * satn * nimg,
+                           sat2 + j * satn * nimg, widths[j]);
         hipLaunchKernelGGL(k_sat_cols, dim3((nx + 64) / 64, nimg), dim3(64), 0, st, ny, nx, sat1 + j * satn * nimg, sat2 + j * satn * nimg,
                            heights[j]);
     }
